@@ -1,0 +1,125 @@
+// Shared declarations of the fcflow HIP engine (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <stdexcept>
+
+#include "../../include/fcflow.h"
+
+namespace fc {
+
+// ---------------------------------------------------------------- errors
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+void set_last_error(const std::string& m);
+
+#define FC_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            throw fc::Error(FC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+constexpr int ROW_PAD = 256;   // row counts of every workspace matrix are padded to this (largest GEMM BM)
+constexpr int COL_PAD = 32;    // feature widths are padded to this (GEMM BK / MFMA tile)
+
+// ---------------------------------------------------------------- device memory owned by a handle
+struct DeviceArena {
+    std::vector<void*> blocks;
+    size_t total = 0;
+    float* alloc_floats(size_t n);
+    float* upload(const std::vector<float>& host);
+    ~DeviceArena();
+};
+
+// ---------------------------------------------------------------- workspace carving (caller-owned memory)
+struct WsCarver {
+    char* base;
+    size_t off = 0, cap;
+    bool dry;
+    WsCarver(void* b, size_t c, bool dry_run) : base((char*)b), cap(c), dry(dry_run) {}
+    float* floats(size_t n) { return (float*)bytes(n * sizeof(float)); }
+    void* bytes(size_t n) {
+        size_t o = round_up_sz(off, 256);
+        off = o + n;
+        if (!dry && off > cap) throw Error(FC_ERR_WORKSPACE, "workspace too small");
+        return dry ? nullptr : (void*)(base + o);
+    }
+};
+
+// ---------------------------------------------------------------- packed Linear (see gemm.h)
+struct PackedLinear {
+    float* W = nullptr;        // [N_alloc][K_pad] row-major, zero padded
+    float* bias = nullptr;     // [N_alloc]
+    float* colvec = nullptr;   // [N_alloc] or null: rank-1 term  C += rowscal[row] * colvec[n]
+    int N_pad = 0;             // columns written (multiple of 32)
+    int K_pad = 0;             // multiple of 32 (sum of segment widths)
+    int seg_k[3] = {0, 0, 0};  // padded K of each A segment
+    int nseg = 0;
+};
+
+// A operand segment: rows x seg_k floats starting at ptr with row pitch lda
+struct ASeg { const float* ptr; int lda; };
+
+enum Epilogue { EPI_LINEAR = 0, EPI_AFFINE = 1, EPI_AUGMENT = 2 };
+
+struct GemmEpi {
+    // EPI_LINEAR
+    int act = FC_ACT_NONE;
+    const float* residual = nullptr; int ldr = 0;
+    const float* rowscal = nullptr;          // [rows] (extra context per point), used with PackedLinear.colvec
+    float* C = nullptr; int ldc = 0;
+    // EPI_AFFINE (W pair-packed [s 32 | t 32] x pairs): in-place y2 = x2*s + t on xbuf, logprob[row] += sum log s
+    // EPI_AUGMENT (W pair-packed [mu 32 | logsigma 32]): z2 = mu + eps*sigma scattered into xbuf, logprob += -log N(z2)
+    float* xbuf = nullptr; int ldx = 0;
+    int x2_col0 = 0;           // AFFINE: first column of x2 inside xbuf
+    int d2 = 0;                // AFFINE: number of transformed dims; AUGMENT: number of noise dims
+    int scale_fn = FC_SCALE_SIGMOID;
+    float* logprob = nullptr;  // [rows_valid]
+    const float* eps = nullptr; int d_in = 0, d1 = 0, d1_pad = 0;   // AUGMENT: latent index = d_in + q ; x1|x2 split
+    float clamp = 0.f;         // AUGMENT/CIF: std clamp (0 = none)
+    int rows_valid = 0;        // rows that exist in user-visible outputs
+};
+
+void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const GemmEpi& e, int epi_kind, hipStream_t s);
+
+// ---------------------------------------------------------------- other kernels (misc.hip / attention.hip / knn.hip)
+void launch_pack_rows(const float* src, int src_ld, int src_cols, float* dst, int dst_ld, int dst_col0, int dst_cols_zero_to,
+                      int rows, hipStream_t s);
+void launch_fill(float* p, float v, size_t n, hipStream_t s);
+void launch_repeat_extra(const float* extra, int X, float* rowscal, int B, int N, hipStream_t s);
+void launch_layernorm(float* h, int ld, int width, int rows, hipStream_t s);   // in place, no affine (folded into q-proj)
+void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
+                      int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, hipStream_t s);
+void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale,
+                         hipStream_t s);
+void launch_base_density(const float* x, int ldx, int d1, int d1_pad, int d2, float* logprob, float log_const,
+                         float* z_out, int D, int rows, hipStream_t s);
+void launch_spline(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows,
+                   int inverse, hipStream_t s);
+void launch_spline_flat(const float* x, const float* params, float* y, float* lad, int64_t n, int K, int inverse, hipStream_t s);
+void launch_knn(const float* f, int ldf, int C, int32_t* idx, int B, int M, int m_stride_rows, int k, hipStream_t s);
+void launch_gather_max(const float* uv, int lduv, int c_out, const int32_t* idx, int k, float* out, int ldo, int out_col0,
+                       int B, int M, int m_stride_rows, hipStream_t s);
+void launch_pool_max_mean(const float* t, int ldt, int width, float* out, int ldo, int B, int M, int m_stride_rows, hipStream_t s);
+
+// ---------------------------------------------------------------- host-side weight table
+struct HostTensor { const float* data; std::vector<int64_t> shape; int64_t numel() const; };
+struct WeightTable {
+    std::map<std::string, HostTensor> t;
+    WeightTable(const fc_tensor* tensors, int n);
+    bool has(const std::string& name) const { return t.count(name) != 0; }
+    const HostTensor& get(const std::string& name) const;
+    const HostTensor& get(const std::string& name, std::initializer_list<int64_t> shape) const;
+};
+
+}  // namespace fc

@@ -1,0 +1,263 @@
+// Host-side helpers: weight table, double-precision folding, packing, device arena.
+#include "hostpack.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace fc {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& m) { g_last_error = m; }
+const char* get_last_error() { return g_last_error.c_str(); }
+
+// ---------------------------------------------------------------- arena
+float* DeviceArena::alloc_floats(size_t n) {
+    void* p = nullptr;
+    FC_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
+    blocks.push_back(p);
+    total += n * sizeof(float);
+    return (float*)p;
+}
+float* DeviceArena::upload(const std::vector<float>& host) {
+    float* d = alloc_floats(host.size());
+    if (!host.empty()) FC_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+DeviceArena::~DeviceArena() {
+    for (void* p : blocks) (void)hipFree(p);
+}
+
+// ---------------------------------------------------------------- weight table
+int64_t HostTensor::numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+}
+WeightTable::WeightTable(const fc_tensor* tensors, int n) {
+    if (n < 0 || (n > 0 && !tensors)) throw Error(FC_ERR_INVALID, "null tensor list");
+    for (int i = 0; i < n; ++i) {
+        const fc_tensor& ft = tensors[i];
+        if (!ft.name || ft.ndim < 0 || ft.ndim > 4) throw Error(FC_ERR_INVALID, "malformed fc_tensor");
+        HostTensor h;
+        h.data = ft.data;
+        for (int d = 0; d < ft.ndim; ++d) h.shape.push_back(ft.shape[d]);
+        if (h.numel() > 0 && !ft.data) throw Error(FC_ERR_INVALID, std::string("tensor without data: ") + ft.name);
+        t[ft.name] = h;
+    }
+}
+const HostTensor& WeightTable::get(const std::string& name) const {
+    auto it = t.find(name);
+    if (it == t.end()) throw Error(FC_ERR_MISSING, "state_dict entry missing: " + name);
+    return it->second;
+}
+const HostTensor& WeightTable::get(const std::string& name, std::initializer_list<int64_t> shape) const {
+    const HostTensor& h = get(name);
+    std::vector<int64_t> want(shape);
+    if (h.shape != want) {
+        std::string s = "state_dict entry " + name + " has shape [";
+        for (auto d : h.shape) s += std::to_string(d) + ",";
+        s += "] expected [";
+        for (auto d : want) s += std::to_string(d) + ",";
+        throw Error(FC_ERR_SHAPE, s + "]");
+    }
+    return h;
+}
+
+// ---------------------------------------------------------------- dense double helpers
+MatD mat_from(const HostTensor& t) {
+    if (t.shape.size() < 2) throw Error(FC_ERR_SHAPE, "expected a matrix");
+    int64_t k = 1;
+    for (size_t d = 1; d < t.shape.size(); ++d) k *= t.shape[d];
+    MatD m((int)t.shape[0], (int)k);
+    for (size_t i = 0; i < m.v.size(); ++i) m.v[i] = t.data[i];
+    return m;
+}
+VecD vec_from(const HostTensor& t) {
+    VecD v((size_t)t.numel());
+    for (size_t i = 0; i < v.size(); ++i) v[i] = t.data[i];
+    return v;
+}
+MatD matmul(const MatD& a, const MatD& b) {
+    if (a.cols != b.rows) throw Error(FC_ERR_SHAPE, "matmul shape mismatch");
+    MatD c(a.rows, b.cols);
+    for (int i = 0; i < a.rows; ++i) {
+        double* ci = &c.v[(size_t)i * c.cols];
+        for (int k = 0; k < a.cols; ++k) {
+            const double aik = a.at(i, k);
+            if (aik == 0.0) continue;
+            const double* bk = &b.v[(size_t)k * b.cols];
+            for (int j = 0; j < b.cols; ++j) ci[j] += aik * bk[j];
+        }
+    }
+    return c;
+}
+MatD expm_double(const MatD& w) {
+    const int n = w.rows;
+    double nrm = 0;
+    for (int i = 0; i < n; ++i) {
+        double r = 0;
+        for (int j = 0; j < n; ++j) r += std::fabs(w.at(i, j));
+        nrm = std::max(nrm, r);
+    }
+    int sq = 0;
+    while (nrm > 0.25) { nrm *= 0.5; ++sq; }
+    MatD x = w;
+    const double sc = std::ldexp(1.0, -sq);
+    for (auto& e : x.v) e *= sc;
+    MatD s(n, n), term(n, n);
+    for (int i = 0; i < n; ++i) { s.at(i, i) = 1.0; term.at(i, i) = 1.0; }
+    for (int k = 1; k <= 24; ++k) {
+        term = matmul(term, x);
+        for (auto& e : term.v) e /= k;
+        for (size_t i = 0; i < s.v.size(); ++i) s.v[i] += term.v[i];
+    }
+    for (int i = 0; i < sq; ++i) s = matmul(s, s);
+    return s;
+}
+double slogdet_abs(const MatD& w) {
+    const int n = w.rows;
+    MatD a = w;
+    double ld = 0;
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r) if (std::fabs(a.at(r, c)) > std::fabs(a.at(piv, c))) piv = r;
+        if (a.at(piv, c) == 0.0) throw Error(FC_ERR_INVALID, "singular permuter matrix");
+        if (piv != c) for (int j = 0; j < n; ++j) std::swap(a.at(piv, j), a.at(c, j));
+        ld += std::log(std::fabs(a.at(c, c)));
+        for (int r = c + 1; r < n; ++r) {
+            const double f = a.at(r, c) / a.at(c, c);
+            if (f != 0.0) for (int j = c; j < n; ++j) a.at(r, j) -= f * a.at(c, j);
+        }
+    }
+    return ld;
+}
+MatD inverse_double(const MatD& w) {
+    const int n = w.rows;
+    MatD a = w, inv(n, n);
+    for (int i = 0; i < n; ++i) inv.at(i, i) = 1.0;
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r) if (std::fabs(a.at(r, c)) > std::fabs(a.at(piv, c))) piv = r;
+        if (a.at(piv, c) == 0.0) throw Error(FC_ERR_INVALID, "singular matrix in inverse");
+        if (piv != c) for (int j = 0; j < n; ++j) { std::swap(a.at(piv, j), a.at(c, j)); std::swap(inv.at(piv, j), inv.at(c, j)); }
+        const double d = 1.0 / a.at(c, c);
+        for (int j = 0; j < n; ++j) { a.at(c, j) *= d; inv.at(c, j) *= d; }
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = a.at(r, c);
+            if (f == 0.0) continue;
+            for (int j = 0; j < n; ++j) { a.at(r, j) -= f * a.at(c, j); inv.at(r, j) -= f * inv.at(c, j); }
+        }
+    }
+    return inv;
+}
+
+// ---------------------------------------------------------------- index maps
+std::vector<int> map_prefix(int n_src, int n_pad) {
+    std::vector<int> m(n_pad, -1);
+    for (int i = 0; i < n_src && i < n_pad; ++i) m[i] = i;
+    return m;
+}
+std::vector<int> map_xlayout(int d1, int d1_pad, int d2, int d2_pad) {
+    std::vector<int> m(d1_pad + d2_pad, -1);
+    for (int i = 0; i < d1; ++i) m[i] = i;
+    for (int j = 0; j < d2; ++j) m[d1_pad + j] = d1 + j;
+    return m;
+}
+std::vector<int> map_pairs(int d2, int second_half_offset) {
+    const int np = (d2 + 31) / 32;
+    std::vector<int> m(np * 64, -1);
+    for (int p = 0; p < np; ++p)
+        for (int c = 0; c < 32; ++c) {
+            const int j = 32 * p + c;
+            if (j < d2) { m[64 * p + c] = j; m[64 * p + 32 + c] = second_half_offset + j; }
+        }
+    return m;
+}
+std::vector<int> map_concat(const std::vector<std::vector<int>>& parts) {
+    std::vector<int> m;
+    for (auto& p : parts) m.insert(m.end(), p.begin(), p.end());
+    return m;
+}
+
+PackedLinear pack_linear(DeviceArena& arena, const MatD& W, const VecD& bias, const VecD& colvec, const std::vector<int>& nmap,
+                         const std::vector<int>& kmap, const std::vector<int>& seg_k) {
+    PackedLinear L;
+    L.N_pad = (int)nmap.size();
+    L.K_pad = (int)kmap.size();
+    if (L.N_pad % 32 || L.K_pad % 32) throw Error(FC_ERR_INVALID, "pack_linear: maps must be padded to 32");
+    int ks = 0;
+    L.nseg = (int)seg_k.size();
+    if (L.nseg < 1 || L.nseg > 3) throw Error(FC_ERR_INVALID, "pack_linear: 1..3 segments");
+    for (int i = 0; i < L.nseg; ++i) { L.seg_k[i] = seg_k[i]; ks += seg_k[i]; }
+    if (ks != L.K_pad) throw Error(FC_ERR_INVALID, "pack_linear: segments do not cover K");
+    std::vector<float> w((size_t)L.N_pad * L.K_pad, 0.f), b(L.N_pad, 0.f), cv(L.N_pad, 0.f);
+    for (int n = 0; n < L.N_pad; ++n) {
+        const int sn = nmap[n];
+        if (sn < 0) continue;
+        if (sn >= W.rows) throw Error(FC_ERR_SHAPE, "pack_linear: row map out of range");
+        float* wr = &w[(size_t)n * L.K_pad];
+        for (int k = 0; k < L.K_pad; ++k) {
+            const int sk = kmap[k];
+            if (sk >= 0) {
+                if (sk >= W.cols) throw Error(FC_ERR_SHAPE, "pack_linear: column map out of range");
+                wr[k] = (float)W.at(sn, sk);
+            }
+        }
+        if (!bias.empty()) b[n] = (float)bias[sn];
+        if (!colvec.empty()) cv[n] = (float)colvec[sn];
+    }
+    L.W = arena.upload(w);
+    L.bias = arena.upload(b);
+    L.colvec = colvec.empty() ? nullptr : arena.upload(cv);
+    return L;
+}
+
+void pack_mlp_mid(DeviceArena& arena, const WeightTable& wt, const std::string& prefix, PackedMLP& out) {
+    out.sizes.clear();
+    out.mid.clear();
+    const HostTensor& w_in = wt.get(prefix + ".in_layer.weight");
+    if (w_in.shape.size() != 2) throw Error(FC_ERR_SHAPE, prefix + ".in_layer.weight must be 2-D");
+    out.sizes.push_back((int)w_in.shape[0]);
+    for (int i = 0;; ++i) {
+        const std::string n = prefix + ".layers." + std::to_string(i);
+        if (!wt.has(n + ".weight")) break;
+        const HostTensor& w = wt.get(n + ".weight");
+        if (w.shape.size() != 2 || w.shape[1] != out.sizes.back()) throw Error(FC_ERR_SHAPE, n + ".weight: input width mismatch");
+        const int no = (int)w.shape[0], ni = (int)w.shape[1];
+        if (i % 2 == 1 && no != out.sizes[out.sizes.size() - 2])
+            throw Error(FC_ERR_SHAPE, n + ": residual add needs matching widths (models/nets.py:27)");
+        wt.get(n + ".bias", {no});
+        out.mid.push_back(pack_linear(arena, mat_from(w), vec_from(wt.get(n + ".bias")), {}, map_prefix(no, round_up(no, 32)),
+                                      map_prefix(ni, round_up(ni, 32)), {round_up(ni, 32)}));
+        out.sizes.push_back(no);
+    }
+    const HostTensor& w_out = wt.get(prefix + ".out_layer.weight");
+    if (w_out.shape.size() != 2 || w_out.shape[1] != out.sizes.back()) throw Error(FC_ERR_SHAPE, prefix + ".out_layer.weight: input width mismatch");
+}
+int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float* rowscal, int act, float* const h[3], int ldh, int rows,
+                           hipStream_t s) {
+    GemmEpi e{};
+    e.act = act; e.C = h[0]; e.ldc = ldh; e.rowscal = rowscal;
+    launch_gemm(m.in_layer, in_segs, rows, e, EPI_LINEAR, s);
+    int cur = 0, keep = -1;
+    for (size_t i = 0; i < m.mid.size(); ++i) {
+        if (i % 2 == 0) keep = cur;                     // even hidden layer: remember its input for the next (odd) layer's residual
+        int nxt = 0;
+        while (nxt == cur || nxt == keep) ++nxt;
+        GemmEpi g{};
+        g.act = act; g.C = h[nxt]; g.ldc = ldh;
+        if (i % 2 == 1) { g.residual = h[keep]; g.ldr = ldh; }
+        ASeg a{h[cur], ldh};
+        launch_gemm(m.mid[i], &a, rows, g, EPI_LINEAR, s);
+        cur = nxt;
+    }
+    return cur;
+}
+int max_hidden_pad(const PackedMLP& m) {
+    int mx = 0;
+    for (int s : m.sizes) mx = std::max(mx, round_up(s, 32));
+    return mx;
+}
+
+}  // namespace fc

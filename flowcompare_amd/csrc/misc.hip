@@ -1,0 +1,324 @@
+// HBM-bound helper kernels of the flow engine: layout packing, LayerNorm, base density, the
+// rational-quadratic spline, DGCNN gather-max and global pooling.  All are one-wave-per-row streaming
+// kernels (coalesced row reads, wave reductions via DPP shuffles); none of them is reshaped into a GEMM.
+#include "common.h"
+
+namespace fc {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------- pack / fill
+// dst[row, dst_col0 + c] = src[row, c] for c < src_cols ; zero for src_cols <= c < zero_to
+__global__ void pack_rows_kernel(const float* __restrict__ src, int src_ld, int src_cols, float* __restrict__ dst, int dst_ld,
+                                 int dst_col0, int zero_to, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    for (int c = lane; c < zero_to; c += 64)
+        dst[(size_t)row * dst_ld + dst_col0 + c] = c < src_cols ? src[(size_t)row * src_ld + c] : 0.f;
+}
+void launch_pack_rows(const float* src, int src_ld, int src_cols, float* dst, int dst_ld, int dst_col0, int zero_to, int rows,
+                      hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, src_ld, src_cols, dst, dst_ld, dst_col0, zero_to, rows);
+    FC_HIP(hipGetLastError());
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) p[i] = v;
+}
+void launch_fill(float* p, float v, size_t n, hipStream_t s) {
+    if (!n) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, v, n);
+    FC_HIP(hipGetLastError());
+}
+
+// extra context [B, X] -> per-point scalar rowscal[b*N + i] = extra[b, 0]   (inner_loop's einops.repeat, X == 1)
+__global__ void repeat_extra_kernel(const float* extra, int X, float* rowscal, int B, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B * N) rowscal[i] = extra[(size_t)(i / N) * X];
+}
+void launch_repeat_extra(const float* extra, int X, float* rowscal, int B, int N, hipStream_t s) {
+    hipLaunchKernelGGL(repeat_extra_kernel, dim3((B * N + 255) / 256), dim3(256), 0, s, extra, X, rowscal, B, N);
+    FC_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- LayerNorm (no affine: gamma/beta are folded into the q projection)
+// models/perceiver.py:18-26 -> torch.nn.LayerNorm(width), biased variance, eps 1e-5.  In place.
+__global__ void layernorm_kernel(float* h, int ld, int width, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* p = h + (size_t)row * ld;
+    float v[16];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < width ? p[c] : 0.f;
+        sum += v[i];
+    }
+    const float mean = wave_sum(sum) / (float)width;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < width ? v[i] - mean : 0.f;
+        sq += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)width + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        if (c < width) p[c] = (v[i] - mean) * rstd;
+    }
+}
+void launch_layernorm(float* h, int ld, int width, int rows, hipStream_t s) {
+    if (width > 1024) throw Error(FC_ERR_UNSUPPORTED, "layernorm: width > 1024");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, ld, width, rows);
+    FC_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- base density + latent export
+// logprob[row] += sum_d(-0.5 log 2pi - 0.5 x_d^2) + log_const   (models/distributions.py:192-195)
+// x is in the engine layout [x1 (d1) | pad | x2 (d2) | pad]; z_out (optional) gets the dense [rows, D] latent.
+__global__ void base_density_kernel(const float* __restrict__ x, int ldx, int d1, int d1_pad, int d2, float* logprob, float log_const,
+                                    float* z_out, int D, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* p = x + (size_t)row * ldx;
+    float acc = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float v = c < d1 ? p[c] : p[d1_pad + (c - d1)];
+        acc += -0.91893853320467274178f - 0.5f * v * v;
+        if (z_out) z_out[(size_t)row * D + c] = v;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) logprob[row] += acc + log_const;
+}
+void launch_base_density(const float* x, int ldx, int d1, int d1_pad, int d2, float* logprob, float log_const, float* z_out, int D,
+                         int rows, hipStream_t s) {
+    hipLaunchKernelGGL(base_density_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, d1, d1_pad, d2, logprob, log_const, z_out, D, rows);
+    FC_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- rational-quadratic spline
+// One element: models/spline_coupling.py:24-66 (tails) + :69-169 (spline) + :17-19 (searchsorted).
+// u points at 3K+1 parameters [K widths | K heights | K+1 derivative logits] with element stride `us`.
+// Quirks reproduced: derivative logits are padded left with log(exp(1-min_d-1)); knot i>=1 uses ud[i-1];
+// ud[K] is never used; last knot + 1e-6 only for the bin search; outside [-3,3] identity with logabsdet 0.
+template <int K>
+__device__ __forceinline__ void rq_spline_elem(float x, const float* u, int us, bool inverse, float& y, float& lad) {
+    constexpr float B = 3.0f, MINW = 1e-3f, MINH = 1e-3f, MIND = 1e-3f;
+    if (!(x >= -B && x <= B)) { y = x; lad = 0.f; return; }
+    float cw[K + 1], ch[K + 1];
+    {
+        float e[K], mx = u[0];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { e[i] = u[i * us]; mx = fmaxf(mx, e[i]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { e[i] = expf(e[i] - mx); sum += e[i]; }
+        float c = 0.f;
+        cw[0] = -B;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { c += MINW + (1.0f - MINW * K) * (e[i] / sum); cw[i + 1] = 2.0f * B * c - B; }
+        cw[K] = B;
+    }
+    {
+        float e[K], mx = u[K * us];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { e[i] = u[(K + i) * us]; mx = fmaxf(mx, e[i]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { e[i] = expf(e[i] - mx); sum += e[i]; }
+        float c = 0.f;
+        ch[0] = -B;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { c += MINH + (1.0f - MINH * K) * (e[i] / sum); ch[i + 1] = 2.0f * B * c - B; }
+        ch[K] = B;
+    }
+    // bin = #{knots <= x} - 1 over the searched knots (last one + 1e-6)
+    int bin = 0;
+#pragma unroll
+    for (int i = 1; i <= K; ++i) {
+        const float knot = (inverse ? ch[i] : cw[i]) + (i == K ? 1e-6f : 0.f);
+        bin += (x >= knot) ? 1 : 0;
+    }
+    float in_cw = cw[0], in_w = cw[1] - cw[0], in_ch = ch[0], in_h = ch[1] - ch[0];
+    float ud0 = 0.f, ud1 = u[(2 * K) * us];
+#pragma unroll
+    for (int i = 1; i < K; ++i) {
+        if (bin == i) {
+            in_cw = cw[i]; in_w = cw[i + 1] - cw[i]; in_ch = ch[i]; in_h = ch[i + 1] - ch[i];
+            ud0 = u[(2 * K + i - 1) * us]; ud1 = u[(2 * K + i) * us];
+        }
+    }
+    const float cst = -1e-3f;                                   // log(exp(1 - min_derivative - 1))
+    const float raw0 = bin == 0 ? cst : ud0;
+    auto softplus = [](float v) { return v > 20.f ? v : log1pf(expf(v)); };
+    const float d0 = MIND + softplus(raw0), d1 = MIND + softplus(ud1);
+    const float delta = in_h / in_w;
+    if (!inverse) {
+        const float th = (x - in_cw) / in_w;
+        const float tt = th * (1.0f - th);
+        const float num = in_h * (delta * th * th + d0 * tt);
+        const float den = delta + (d0 + d1 - 2.0f * delta) * tt;
+        y = in_ch + num / den;
+        const float omt = 1.0f - th;
+        const float dnum = delta * delta * (d1 * th * th + 2.0f * delta * tt + d0 * omt * omt);
+        lad = logf(dnum) - 2.0f * logf(den);
+    } else {
+        const float dy = x - in_ch;
+        const float t3 = d0 + d1 - 2.0f * delta;
+        const float qa = dy * t3 + in_h * (delta - d0);
+        const float qb = in_h * d0 - dy * t3;
+        const float qc = -delta * dy;
+        const float disc = qb * qb - 4.0f * qa * qc;
+        const float root = (2.0f * qc) / (-qb - sqrtf(disc));
+        y = root * in_w + in_cw;
+        const float tt = root * (1.0f - root);
+        const float den = delta + t3 * tt;
+        const float omr = 1.0f - root;
+        const float dnum = delta * delta * (d1 * root * root + 2.0f * delta * tt + d0 * omr * omr);
+        lad = -(logf(dnum) - 2.0f * logf(den));
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void rq_dispatch(float x, const float* u, int us, bool inv, float& y, float& lad) {
+    rq_spline_elem<K>(x, u, us, inv, y, lad);
+}
+
+__device__ __forceinline__ void rq_any(int K, float x, const float* u, int us, bool inv, float& y, float& lad) {
+    switch (K) {
+        case 4: rq_dispatch<4>(x, u, us, inv, y, lad); break;
+        case 8: rq_dispatch<8>(x, u, us, inv, y, lad); break;
+        case 16: rq_dispatch<16>(x, u, us, inv, y, lad); break;
+        default: y = x; lad = 0.f; break;     // rejected on the host
+    }
+}
+
+// One wave per point row: the row's (3K+1)*d2 parameters are staged in LDS with coalesced loads, then lane j
+// handles dims j, j+64, ... (LDS stride 3K+1 floats is odd -> conflict-free).  y2 overwrites x2 in place;
+// forward adds the row's sum of logabsdet to logprob.
+__global__ __launch_bounds__(256) void spline_rows_kernel(const float* __restrict__ params, int ldp, float* xbuf, int ldx, int x2_col0,
+                                                          int d2, int K, float* logprob, int rows, int inverse) {
+    extern __shared__ float sp[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    const int npar = (3 * K + 1) * d2;
+    float* mine = sp + (size_t)wave * ((npar + 3) & ~3);
+    if (row < rows) {
+        const float* src = params + (size_t)row * ldp;
+        for (int c = lane * 4; c < npar; c += 256) {           // ldp and npar rounded so that float4 loads stay in the row
+            const float4 t = *reinterpret_cast<const float4*>(src + c);
+            *reinterpret_cast<float4*>(mine + c) = t;
+        }
+    }
+    __syncthreads();
+    if (row >= rows) return;
+    float acc = 0.f;
+    float* xr = xbuf + (size_t)row * ldx + x2_col0;
+    for (int j = lane; j < d2; j += 64) {
+        float y, lad;
+        rq_any(K, xr[j], mine + j * (3 * K + 1), 1, inverse != 0, y, lad);
+        xr[j] = y;
+        acc += lad;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && !inverse) logprob[row] += acc;
+}
+void launch_spline(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows, int inverse,
+                   hipStream_t s) {
+    if (K != 4 && K != 8 && K != 16) throw Error(FC_ERR_UNSUPPORTED, "spline: num_bins_spline must be 4, 8 or 16");
+    const int npar = (3 * K + 1) * d2;
+    if (ldp < ((npar + 3) & ~3) || ldp % 4 != 0) throw Error(FC_ERR_INVALID, "spline: parameter pitch too small");
+    const size_t lds = 4 * (size_t)((npar + 3) & ~3) * sizeof(float);
+    if (lds > 160 * 1024) throw Error(FC_ERR_UNSUPPORTED, "spline: (3K+1)*d2 too large for the LDS-staged kernel");
+    static bool attr_done = false;
+    if (!attr_done) {
+        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spline_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(spline_rows_kernel, dim3((rows + 3) / 4), dim3(256), lds, s, params, ldp, xbuf, ldx, x2_col0, d2, K, logprob, rows, inverse);
+    FC_HIP(hipGetLastError());
+}
+
+__global__ void spline_flat_kernel(const float* x, const float* params, float* y, float* lad, int64_t n, int K, int inverse) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float yy, ll;
+    rq_any(K, x[i], params + i * (3 * K + 1), 1, inverse != 0, yy, ll);
+    y[i] = yy;
+    lad[i] = ll;
+}
+void launch_spline_flat(const float* x, const float* params, float* y, float* lad, int64_t n, int K, int inverse, hipStream_t s) {
+    if (K != 4 && K != 8 && K != 16) throw Error(FC_ERR_UNSUPPORTED, "spline: num_bins_spline must be 4, 8 or 16");
+    if (n <= 0) return;
+    hipLaunchKernelGGL(spline_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, params, y, lad, n, K, inverse);
+    FC_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------- DGCNN edge-conv tail
+// out[p, c] = LeakyReLU_0.2( max_j u[idx[p, j], c] + v[p, c] ), uv rows = [u (c_out) | v (c_out)].
+// Equals conv(cat(nbr - x, x)) -> BN -> LeakyReLU -> max_k of models/pytorch_gcn.py:23-47,85-99 because the 1x1 conv is
+// linear (W1 nbr + (W2 - W1) x), eval BN is a per-channel affine map folded into u and v, and LeakyReLU is monotone.
+__global__ void gather_max_kernel(const float* __restrict__ uv, int lduv, int c_out, const int32_t* __restrict__ idx, int k,
+                                  float* out, int ldo, int out_col0, int M, int m_stride, int total) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= total) return;
+    const int b = p / M, i = p - b * M;
+    const size_t base = (size_t)b * m_stride;
+    const int32_t* ip = idx + ((size_t)b * M + i) * k;
+    for (int c = lane; c < c_out; c += 64) {
+        float mx = -INFINITY;
+        for (int j = 0; j < k; ++j) mx = fmaxf(mx, uv[(base + ip[j]) * lduv + c]);
+        const float t = mx + uv[(base + i) * lduv + c_out + c];
+        out[(base + i) * ldo + out_col0 + c] = t > 0.f ? t : 0.2f * t;
+    }
+}
+void launch_gather_max(const float* uv, int lduv, int c_out, const int32_t* idx, int k, float* out, int ldo, int out_col0, int B, int M,
+                       int m_stride_rows, hipStream_t s) {
+    const int total = B * M;
+    hipLaunchKernelGGL(gather_max_kernel, dim3((total + 3) / 4), dim3(256), 0, s, uv, lduv, c_out, idx, k, out, ldo, out_col0, M, m_stride_rows, total);
+    FC_HIP(hipGetLastError());
+}
+
+// global embedder pooling: out[b] = [max_i t[b,i,:] | mean_i t[b,i,:]]  (models/pytorch_gcn.py:178-182)
+__global__ void pool_max_mean_kernel(const float* __restrict__ t, int ldt, int width, float* out, int ldo, int M, int m_stride) {
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;   // 4 row-partitions per block
+    __shared__ float smx[4][64], ssum[4][64];
+    float mx = -INFINITY, sum = 0.f;
+    if (c < width)
+        for (int i = part; i < M; i += 4) {
+            const float v = t[((size_t)b * m_stride + i) * ldt + c];
+            mx = fmaxf(mx, v);
+            sum += v;
+        }
+    smx[part][threadIdx.x & 63] = mx;
+    ssum[part][threadIdx.x & 63] = sum;
+    __syncthreads();
+    if (part == 0 && c < width) {
+        const int l = threadIdx.x;
+        out[(size_t)b * ldo + c] = fmaxf(fmaxf(smx[0][l], smx[1][l]), fmaxf(smx[2][l], smx[3][l]));
+        out[(size_t)b * ldo + width + c] = ((ssum[0][l] + ssum[1][l]) + (ssum[2][l] + ssum[3][l])) / (float)M;
+    }
+}
+void launch_pool_max_mean(const float* t, int ldt, int width, float* out, int ldo, int B, int M, int m_stride_rows, hipStream_t s) {
+    hipLaunchKernelGGL(pool_max_mean_kernel, dim3((width + 63) / 64, B), dim3(256), 0, s, t, ldt, width, out, ldo, M, m_stride_rows);
+    FC_HIP(hipGetLastError());
+}
+
+}  // namespace fc

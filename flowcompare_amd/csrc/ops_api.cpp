@@ -1,0 +1,87 @@
+// Single-operator entry points of the C ABI (fc_op_*): the SAME kernels the engines launch, wrapped so that
+// unit-level parity tests can drive them with dense tensors.  These wrappers allocate temporary device
+// memory for the padded layouts (they are test/diagnostic conveniences, not the hot path).
+#include <memory>
+
+#include "hostpack.h"
+
+namespace fc {
+void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale, hipStream_t s);
+
+struct TmpBuf {
+    void* p = nullptr;
+    explicit TmpBuf(size_t bytes) { FC_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
+    ~TmpBuf() { (void)hipFree(p); }
+    float* f() const { return (float*)p; }
+};
+}  // namespace fc
+
+#define FC_API_BEGIN try {
+#define FC_API_END                                                    \
+    }                                                                 \
+    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }          \
+    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; } \
+    return FC_OK;
+
+extern "C" {
+
+int fc_op_linear_f32(const float* x, const float* W, const float* bias, const float* residual, float* y, int32_t rows, int32_t N, int32_t K,
+                     int32_t act, void* stream) {
+    FC_API_BEGIN
+    using namespace fc;
+    if (!x || !W || !y || rows < 1 || N < 1 || K < 1) throw Error(FC_ERR_INVALID, "fc_op_linear_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int rp = round_up(rows, ROW_PAD), np = round_up(N, 32), kp = round_up(K, 32);
+    TmpBuf xp((size_t)rp * kp * 4), wp((size_t)np * kp * 4), bp((size_t)np * 4), cp((size_t)rp * np * 4), rpad(residual ? (size_t)rp * np * 4 : 4);
+    launch_fill(xp.f(), 0.f, (size_t)rp * kp, s);
+    launch_fill(wp.f(), 0.f, (size_t)np * kp, s);
+    launch_fill(bp.f(), 0.f, (size_t)np, s);
+    launch_pack_rows(x, K, K, xp.f(), kp, 0, K, rows, s);
+    launch_pack_rows(W, K, K, wp.f(), kp, 0, K, N, s);
+    if (bias) launch_pack_rows(bias, N, N, bp.f(), np, 0, N, 1, s);
+    if (residual) {
+        launch_fill(rpad.f(), 0.f, (size_t)rp * np, s);
+        launch_pack_rows(residual, N, N, rpad.f(), np, 0, N, rows, s);
+    }
+    PackedLinear L;
+    L.W = wp.f(); L.bias = bp.f(); L.N_pad = np; L.K_pad = kp; L.nseg = 1; L.seg_k[0] = kp;
+    GemmEpi e{};
+    e.act = act; e.C = cp.f(); e.ldc = np;
+    if (residual) { e.residual = rpad.f(); e.ldr = np; }
+    ASeg a{xp.f(), kp};
+    launch_gemm(L, &a, rp, e, EPI_LINEAR, s);
+    launch_pack_rows(cp.f(), np, N, y, N, 0, N, rows, s);
+    FC_HIP(hipStreamSynchronize(s));
+    FC_API_END
+}
+
+int fc_op_attention_f32(const float* q, const float* k, const float* v, float* out, int32_t B, int32_t N, int32_t M, int32_t D, float scale,
+                        void* stream) {
+    FC_API_BEGIN
+    if (!q || !k || !v || !out) throw fc::Error(FC_ERR_INVALID, "fc_op_attention_f32: null pointer");
+    if (D != 32 && D != 64 && D != 128) throw fc::Error(FC_ERR_UNSUPPORTED, "fc_op_attention_f32: D must be 32, 64 or 128");
+    fc::launch_attention_op(q, k, v, out, B, N, M, D, scale, (hipStream_t)stream);
+    FC_API_END
+}
+
+int fc_op_knn_f32(const float* f, int32_t* idx, int32_t B, int32_t M, int32_t C, int32_t k, void* stream) {
+    FC_API_BEGIN
+    using namespace fc;
+    if (!f || !idx || B < 1 || M < 1 || C < 1) throw Error(FC_ERR_INVALID, "fc_op_knn_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int cp = round_up(C, 32);
+    TmpBuf fp((size_t)B * M * cp * 4);
+    launch_pack_rows(f, C, C, fp.f(), cp, 0, cp, B * M, s);
+    launch_knn(fp.f(), cp, C, idx, B, M, M, k, s);
+    FC_HIP(hipStreamSynchronize(s));
+    FC_API_END
+}
+
+int fc_op_rqspline_f32(const float* x, const float* params, float* y, float* logabsdet, int64_t n, int32_t K, int32_t inverse, void* stream) {
+    FC_API_BEGIN
+    if (!x || !params || !y || !logabsdet || n < 0) throw fc::Error(FC_ERR_INVALID, "fc_op_rqspline_f32: bad argument");
+    fc::launch_spline_flat(x, params, y, logabsdet, n, K, inverse, (hipStream_t)stream);
+    FC_API_END
+}
+
+}  // extern "C"

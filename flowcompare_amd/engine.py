@@ -1,0 +1,282 @@
+"""ctypes binding of libfcflow.so (include/fcflow.h) + the handles the nn.Module mirrors use.
+
+PyTorch is plumbing here: device memory (tensors), the current HIP stream and torch.distributed.  Every function
+below hands raw device pointers to the C ABI; nothing is computed in PyTorch and there is no CPU fallback —
+a missing or unloadable library raises immediately.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfcflow.so")
+ABI_VERSION = 1
+
+FLOW_TYPES = {"AffineCoupling": 0, "RationalQuadraticSplineCoupling": 1, "ExponentialCoupling": 2}
+SCALE_FNS = {"exp": 0, "sigmoid": 1}
+ACTS = {"GELU": 1, "RELU": 2, "ELU": 3}
+PERMUTERS = {"LinearLU": 0, "random_permute": 1, "FullCombiner": 2, "ExponentialCombiner": 3}
+EXPM = {"torch": 0, "original": 1}
+
+EXPORTS = [
+    "fc_abi_version", "fc_last_error",
+    "fc_flow_create", "fc_flow_destroy", "fc_flow_workspace_bytes", "fc_flow_noise_count", "fc_flow_noise_width",
+    "fc_flow_logprob_f32", "fc_flow_inverse_f32",
+    "fc_dgcnn_create", "fc_dgcnn_destroy", "fc_dgcnn_out_dim", "fc_dgcnn_workspace_bytes", "fc_dgcnn_embed_f32",
+    "fc_op_linear_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
+]
+
+
+class FcTensor(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.c_void_p), ("ndim", ctypes.c_int32), ("shape", ctypes.c_int64 * 4)]
+
+
+class FcFlowConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "struct_size", "input_dim", "latent_dim", "cif_latent_dim", "n_flow_layers", "flow_type", "affine_scale_fn",
+        "permuter_type", "act_norm", "nonlinearity", "global_context", "extra_context_dim", "input_embedding_dim",
+        "num_bins_spline", "expm_algo")] + [(n, ctypes.c_float) for n in ("linear_lu_eps", "eps_expm", "clamp_dist")]
+
+
+class FcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libfcflow error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads libfcflow.so once; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python -m flowcompare_amd.build` "
+                               "(flowcompare_amd has no PyTorch/CPU fallback for the flow)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.fc_last_error.restype = ctypes.c_char_p
+        L.fc_flow_destroy.restype = None
+        L.fc_dgcnn_destroy.restype = None
+        if L.fc_abi_version() != ABI_VERSION:
+            raise RuntimeError("libfcflow.so ABI version mismatch: rebuild with `python -m flowcompare_amd.build --force`")
+        _lib = L
+    return _lib
+
+
+def _check(code):
+    if code != 0:
+        raise FcError(code, lib().fc_last_error().decode())
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(t, device=None):
+    t = t.detach()
+    if device is not None:
+        t = t.to(device)
+    if not t.is_cuda:
+        raise RuntimeError("flowcompare_amd: tensors must live on a HIP device (there is no CPU path)")
+    return t.to(torch.float32).contiguous()
+
+
+def params_version(module):
+    """Changes whenever a parameter/buffer is modified in place or replaced (engine re-pack trigger)."""
+    return tuple((id(t), t._version) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def _tensor_table(state_dict):
+    """state_dict -> (ctypes array of fc_tensor, keep-alive list): host fp32 copies, integer buffers as floats."""
+    keep, items = [], []
+    for name, t in state_dict.items():
+        h = t.detach().to("cpu", torch.float32).contiguous()
+        if h.dim() > 4:
+            raise RuntimeError(f"state_dict entry {name} has more than 4 dims")
+        ft = FcTensor()
+        nb = name.encode()
+        ft.name = nb
+        ft.data = h.data_ptr()
+        ft.ndim = h.dim()
+        for i, s in enumerate(h.shape):
+            ft.shape[i] = s
+        keep += [h, nb]
+        items.append(ft)
+    arr = (FcTensor * len(items))(*items)
+    return arr, keep
+
+
+class _Workspace:
+    """Grow-only device scratch owned by a handle (the C ABI never allocates inside compute calls)."""
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+class FlowHandle:
+    """fc_flow wrapper: replaces the compute of models.Flow (reference models/transform.py:61-84)."""
+
+    def __init__(self, config, state_dict, version, device):
+        self.version = version
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("flowcompare_amd: the flow must be on a HIP device (`.to('cuda')`); there is no CPU path")
+        c = FcFlowConfig()
+        c.struct_size = ctypes.sizeof(FcFlowConfig)
+        c.input_dim, c.latent_dim, c.cif_latent_dim = config["input_dim"], config["latent_dim"], config["cif_latent_dim"]
+        c.n_flow_layers = config["n_flow_layers"]
+        c.flow_type = FLOW_TYPES[config["flow_type"]]
+        c.affine_scale_fn = SCALE_FNS[config["affine_scale_fn"]]
+        c.permuter_type = PERMUTERS[config["permuter_type"]]
+        c.act_norm = int(bool(config["act_norm"]))
+        c.nonlinearity = ACTS[config["coupling_block_nonlinearity"]]
+        c.global_context = int(bool(config["global"]))
+        c.extra_context_dim = int(config["extra_context_dim"])
+        c.input_embedding_dim = config["input_embedding_dim"]
+        c.num_bins_spline = config["num_bins_spline"]
+        c.expm_algo = EXPM[config["coupling_expm_algo"]]
+        c.linear_lu_eps, c.eps_expm = float(config["linear_lu_eps"]), float(config["eps_expm"])
+        c.clamp_dist = float(config["clamp_dist"] or 0.0)
+        self.latent_dim, self.input_dim, self.X = c.latent_dim, c.input_dim, c.extra_context_dim
+        arr, keep = _tensor_table(state_dict)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(lib().fc_flow_create(ctypes.byref(c), arr, len(arr), ctypes.byref(self._h)))
+        del keep
+        self._ws = _Workspace()
+        self.n_noise = lib().fc_flow_noise_count(self._h)
+        self.noise_width = [lib().fc_flow_noise_width(self._h, i) for i in range(self.n_noise)]
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.fc_flow_destroy(self._h)
+            self._h = None
+
+    def _prep(self, x, context, extra_context, eps):
+        B, N = x.shape[0], x.shape[1]
+        x = _dev_f32(x)
+        ctx = _dev_f32(context)
+        M = ctx.shape[1]
+        extra = None
+        if self.X:
+            if extra_context is None:
+                raise RuntimeError("this flow was built with extra context (extra_z_value_context) but extra_context is None")
+            if extra_context.dim() == 3:                     # [B,n,X] as produced by inner_loop's repeat: constant over n
+                if extra_context.shape[1] != N:
+                    raise RuntimeError(f"Sizes of tensors must match: extra_context has {extra_context.shape[1]} points, x has {N} "
+                                       "(extra_context is repeated to config['sample_size'], reference model_initialization.py:213)")
+                extra_context = extra_context[:, 0, :]
+            extra = _dev_f32(extra_context)
+        eps = [_dev_f32(e) for e in (eps or [])]
+        if len(eps) != self.n_noise:
+            raise RuntimeError(f"flow needs {self.n_noise} noise tensors, got {len(eps)}")
+        for e, wdt in zip(eps, self.noise_width):
+            if tuple(e.shape) != (B, N, wdt):
+                raise RuntimeError(f"noise tensor has shape {tuple(e.shape)}, expected {(B, N, wdt)}")
+        return x, ctx, extra, eps, B, N, M
+
+    def log_prob(self, x, context, extra_context, eps, return_latent=False):
+        x, ctx, extra, eps, B, N, M = self._prep(x, context, extra_context, eps)
+        L = lib()
+        with torch.cuda.device(self.device):
+            need = ctypes.c_size_t()
+            _check(L.fc_flow_workspace_bytes(self._h, B, N, M, ctypes.byref(need)))
+            ws = self._ws.get(need.value, self.device)
+            out = torch.empty(B, N, dtype=torch.float32, device=self.device)
+            z = torch.empty(B, N, self.latent_dim, dtype=torch.float32, device=self.device) if return_latent else None
+            eps_arr = (ctypes.c_void_p * max(1, len(eps)))(*[e.data_ptr() for e in eps])
+            _check(L.fc_flow_logprob_f32(self._h, _ptr(x), _ptr(ctx), _ptr(extra), eps_arr, len(eps), _ptr(out), _ptr(z),
+                                         B, N, M, _ptr(ws), ctypes.c_size_t(ws.numel()), _stream()))
+        return (out, z) if return_latent else out
+
+    def inverse(self, z, context, extra_context, eps):
+        raise FcError(6, "fc_flow_inverse_f32: the sampling path (SURVEY.md §8f N2) is not built yet")
+
+
+class DgcnnHandle:
+    """fc_dgcnn wrapper: replaces models.DGCNNembedder / DGCNNembedderGlobal forward (reference models/pytorch_gcn.py:81-188)."""
+
+    def __init__(self, n_neighbors, is_global, state_dict, version, device):
+        self.version = version
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("flowcompare_amd: the embedder must be on a HIP device (`.to('cuda')`); there is no CPU path")
+        self.is_global = bool(is_global)
+        arr, keep = _tensor_table(state_dict)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(lib().fc_dgcnn_create(int(n_neighbors), int(self.is_global), arr, len(arr), ctypes.byref(self._h)))
+        del keep
+        self.out_dim = lib().fc_dgcnn_out_dim(self._h)
+        self._ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.fc_dgcnn_destroy(self._h)
+            self._h = None
+
+    def embed(self, pts):
+        pts = _dev_f32(pts)
+        B, M = pts.shape[0], pts.shape[1]
+        L = lib()
+        with torch.cuda.device(self.device):
+            need = ctypes.c_size_t()
+            _check(L.fc_dgcnn_workspace_bytes(self._h, B, M, ctypes.byref(need)))
+            ws = self._ws.get(need.value, self.device)
+            shape = (B, self.out_dim) if self.is_global else (B, M, self.out_dim)
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+            _check(L.fc_dgcnn_embed_f32(self._h, _ptr(pts), _ptr(out), B, M, _ptr(ws), ctypes.c_size_t(ws.numel()), _stream()))
+        return out
+
+
+# ---------------------------------------------------------------- single operators (unit-level parity tests)
+def op_linear(x, W, bias=None, residual=None, act="none"):
+    code = {"none": 0, "gelu": 1, "relu": 2, "elu": 3, "lrelu": 4}[act]
+    x, W = _dev_f32(x), _dev_f32(W)
+    rows, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(rows, N, dtype=torch.float32, device=x.device)
+    b = _dev_f32(bias) if bias is not None else None
+    r = _dev_f32(residual) if residual is not None else None
+    with torch.cuda.device(x.device):
+        _check(lib().fc_op_linear_f32(_ptr(x), _ptr(W), _ptr(b), _ptr(r), _ptr(y), rows, N, K, code, _stream()))
+    return y
+
+
+def op_attention(q, k, v, scale):
+    q, k, v = _dev_f32(q), _dev_f32(k), _dev_f32(v)
+    B, N, D = q.shape
+    M = k.shape[1]
+    out = torch.empty_like(q)
+    with torch.cuda.device(q.device):
+        _check(lib().fc_op_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, N, M, D, ctypes.c_float(scale), _stream()))
+    return out
+
+
+def op_knn(f, k):
+    f = _dev_f32(f)
+    B, M, C = f.shape
+    idx = torch.empty(B, M, k, dtype=torch.int32, device=f.device)
+    with torch.cuda.device(f.device):
+        _check(lib().fc_op_knn_f32(_ptr(f), _ptr(idx), B, M, C, k, _stream()))
+    return idx
+
+
+def op_rqspline(x, params, num_bins, inverse=False):
+    x, params = _dev_f32(x), _dev_f32(params)
+    n = x.numel()
+    assert params.numel() == n * (3 * num_bins + 1)
+    y, lad = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _check(lib().fc_op_rqspline_f32(_ptr(x), _ptr(params), _ptr(y), _ptr(lad), ctypes.c_int64(n), num_bins, int(inverse), _stream()))
+    return y, lad

@@ -1,0 +1,148 @@
+/*
+ * fcflow.h — C ABI of the MI355X-native FlowCompare forward log-prob engine (libfcflow.so).
+ *
+ * The reference (SamGalanakis/FlowCompare) has NO FFI seam on this path: the seam is Python
+ * (`models_dict` + `inner_loop`, model_initialization.py:206-228).  This header is therefore the
+ * boundary a maintainer would bind with ctypes; each entry point names the
+ * reference interface it replaces.  Conventions:
+ *   - plain C, opaque handles, caller-owned DEVICE buffers, explicit HIP stream (void* = hipStream_t),
+ *     no hidden allocation inside the compute calls (the caller provides the workspace);
+ *   - every function returns an int status (FC_OK == 0); fc_last_error() gives the message.
+ *     Nothing in the library calls exit()/abort() (the reference's vendored CUDA helpers do,
+ *     lib/paconv_lib/src/gpu/cuda_utils.h:32-41 — deliberately not reproduced);
+ *   - a handle is immutable after create; concurrent calls on one handle must use distinct
+ *     workspaces; all tensors are fp32, contiguous, channels-last [B, points, features].
+ *   - weights are handed over as the reference checkpoint's state_dict entries (name, shape, host
+ *     pointer); folding / padding / packing for the kernels happens inside create.
+ */
+#ifndef FCFLOW_H
+#define FCFLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FC_ABI_VERSION 1
+
+enum fc_status {
+    FC_OK = 0,
+    FC_ERR_INVALID = 1,      /* bad argument / inconsistent config            */
+    FC_ERR_MISSING = 2,      /* a state_dict entry the config needs is absent */
+    FC_ERR_SHAPE = 3,        /* a tensor has the wrong shape                  */
+    FC_ERR_WORKSPACE = 4,    /* workspace too small                           */
+    FC_ERR_HIP = 5,          /* HIP runtime error                             */
+    FC_ERR_UNSUPPORTED = 6   /* valid reference config this build does not cover yet */
+};
+
+/* One state_dict entry in HOST memory.  Integer buffers (Permuter.permutation) are passed as floats. */
+typedef struct fc_tensor {
+    const char* name;
+    const float* data;
+    int32_t ndim;
+    int64_t shape[4];
+} fc_tensor;
+
+enum fc_flow_type { FC_FLOW_AFFINE = 0, FC_FLOW_SPLINE = 1, FC_FLOW_EXPONENTIAL = 2 };
+enum fc_scale_fn { FC_SCALE_EXP = 0, FC_SCALE_SIGMOID = 1 };
+enum fc_act { FC_ACT_NONE = 0, FC_ACT_GELU = 1, FC_ACT_RELU = 2, FC_ACT_ELU = 3, FC_ACT_LRELU02 = 4 };
+enum fc_permuter { FC_PERM_LINEAR_LU = 0, FC_PERM_RANDOM = 1, FC_PERM_FULL = 2, FC_PERM_EXPONENTIAL = 3 };
+enum fc_expm_algo { FC_EXPM_TORCH = 0, FC_EXPM_ORIGINAL = 1 };
+
+/* Scalar part of the reference config dict (config/<name>.yaml keys; layer widths are read from the tensor shapes). */
+typedef struct fc_flow_config {
+    int32_t struct_size;          /* sizeof(fc_flow_config), ABI check                         */
+    int32_t input_dim;            /* 'input_dim' (6)                                           */
+    int32_t latent_dim;           /* 'latent_dim'                                              */
+    int32_t cif_latent_dim;       /* 'cif_latent_dim' (== latent_dim: plain PreConditionApplier) */
+    int32_t n_flow_layers;        /* 'n_flow_layers'                                           */
+    int32_t flow_type;            /* enum fc_flow_type  <- 'flow_type'                          */
+    int32_t affine_scale_fn;      /* enum fc_scale_fn   <- 'affine_scale_fn'                    */
+    int32_t permuter_type;        /* enum fc_permuter   <- 'permuter_type'                      */
+    int32_t act_norm;             /* 'act_norm'                                                */
+    int32_t nonlinearity;         /* enum fc_act        <- 'coupling_block_nonlinearity'        */
+    int32_t global_context;       /* config['global'] (DGCNNembedderGlobal), model_initialization.py:42-45 */
+    int32_t extra_context_dim;    /* config['extra_context_dim'] (0 or 1), model_initialization.py:33-39   */
+    int32_t input_embedding_dim;  /* 'input_embedding_dim' (E)                                 */
+    int32_t num_bins_spline;      /* 'num_bins_spline'                                         */
+    int32_t expm_algo;            /* enum fc_expm_algo  <- 'coupling_expm_algo'                 */
+    float linear_lu_eps;          /* 'linear_lu_eps'                                           */
+    float eps_expm;               /* 'eps_expm'                                                */
+    float clamp_dist;             /* 'clamp_dist' (CIF augment/slice std clamp)                */
+} fc_flow_config;
+
+typedef struct fc_flow fc_flow;      /* replaces models.Flow (models/transform.py:61-84)         */
+typedef struct fc_dgcnn fc_dgcnn;    /* replaces models.DGCNNembedder(Global) (models/pytorch_gcn.py:50-188) */
+
+int fc_abi_version(void);
+const char* fc_last_error(void);     /* thread-local, valid until the next failing call on this thread */
+
+/* ---- flow: Flow.log_prob / Flow.sample ------------------------------------------------------- */
+
+/* Builds the device-resident, kernel-packed flow from the checkpoint tensors `flow.state_dict()`
+ * (replaces the module graph initialize_flow assembles, model_initialization.py:136-160). */
+int fc_flow_create(const fc_flow_config* cfg, const fc_tensor* tensors, int32_t n_tensors, fc_flow** out);
+void fc_flow_destroy(fc_flow* flow);
+
+/* Bytes of device workspace fc_flow_logprob_f32 / fc_flow_inverse_f32 need for (B, N, M). */
+int fc_flow_workspace_bytes(const fc_flow* flow, int32_t B, int32_t N, int32_t M, size_t* bytes);
+
+/* Number of noise tensors one forward consumes and the feature width of tensor i ([B,N,width]):
+ * the augmenter's rsample() (models/augmenter.py:49-63) and one per CIF block (models/cif_block.py:74).
+ * Making eps an explicit input is what makes the stochastic forward reproducible. */
+int fc_flow_noise_count(const fc_flow* flow);
+int fc_flow_noise_width(const fc_flow* flow, int32_t i);
+
+/* Flow.log_prob (models/transform.py:70-76):
+ *   x        [B,N,input_dim]        target points
+ *   ctx      [B,M,E]                per-point context embedding (attention keys/values); in global
+ *                                   mode the reference passes the embedding repeated to [B,N,E], so M == N
+ *   extra    [B,X] or NULL          extra context, constant per scene (inner_loop repeats it over N)
+ *   eps      n_eps device pointers  noise, eps[i] is [B,N,fc_flow_noise_width(i)]
+ *   logprob  [B,N]       (out)      log p(x | ctx) in nats
+ *   z_out    [B,N,latent_dim] or NULL (out) latent after the last transform (diagnostics / tests) */
+int fc_flow_logprob_f32(fc_flow* flow, const float* x, const float* ctx, const float* extra,
+                        const float* const* eps, int32_t n_eps, float* logprob, float* z_out,
+                        int32_t B, int32_t N, int32_t M, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Inverse pass of Flow.sample (models/transform.py:79-84) from a caller-drawn latent z [B,N,latent_dim]
+ * -> x_out [B,N,input_dim].  eps: one tensor per CIF block (Slice.inverse draws, models/slice.py:46-58). */
+int fc_flow_inverse_f32(fc_flow* flow, const float* z, const float* ctx, const float* extra,
+                        const float* const* eps, int32_t n_eps, float* x_out,
+                        int32_t B, int32_t N, int32_t M, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- DGCNN context embedder: input_embedder(extract_0) --------------------------------------- */
+int fc_dgcnn_create(int32_t n_neighbors, int32_t global_pool, const fc_tensor* tensors, int32_t n_tensors, fc_dgcnn** out);
+void fc_dgcnn_destroy(fc_dgcnn* emb);
+int fc_dgcnn_out_dim(const fc_dgcnn* emb);
+int fc_dgcnn_workspace_bytes(const fc_dgcnn* emb, int32_t B, int32_t M, size_t* bytes);
+/* pts [B,M,C_in] -> out [B,M,E] (per-point) or [B,E] (global_pool); eval-mode BatchNorm (running stats). */
+int fc_dgcnn_embed_f32(fc_dgcnn* emb, const float* pts, float* out, int32_t B, int32_t M,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- single operators (same kernels as above; exported for unit-level parity tests) ---------- */
+
+/* y[rows,N] = act( x[rows,K] @ W[N,K]^T + bias + residual ), torch.nn.functional.linear semantics
+ * (models/nets.py:19-30 building block).  bias / residual may be NULL.  All DEVICE pointers, dense row-major. */
+int fc_op_linear_f32(const float* x, const float* W, const float* bias, const float* residual, float* y,
+                     int32_t rows, int32_t N, int32_t K, int32_t act, void* stream);
+
+/* out[B,N,D] = softmax(q k^T * scale) v  with q [B,N,D], k,v [B,M,D]  (models/perceiver.py:106-113). */
+int fc_op_attention_f32(const float* q, const float* k, const float* v, float* out,
+                        int32_t B, int32_t N, int32_t M, int32_t D, float scale, void* stream);
+
+/* k nearest neighbours in feature space, reference ranking -|xi|^2 + 2 xi.xj - |xj|^2 (self included)
+ * (models/pytorch_gcn.py:13-20).  f [B,M,C] channels-last -> idx [B,M,k] int32 (unordered set). */
+int fc_op_knn_f32(const float* f, int32_t* idx, int32_t B, int32_t M, int32_t C, int32_t k, void* stream);
+
+/* Elementwise rational-quadratic spline with linear tails (models/spline_coupling.py:24-169).
+ * x [n], params [n, 3K+1] laid out [K widths | K heights | K+1 derivatives] -> y [n], logabsdet [n]. */
+int fc_op_rqspline_f32(const float* x, const float* params, float* y, float* logabsdet,
+                       int64_t n, int32_t K, int32_t inverse, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCFLOW_H */

@@ -1,0 +1,101 @@
+"""Pins the CPU oracle (oracle/flow_oracle.py) to golden vectors produced by RUNNING THE REFERENCE
+(tests/golden/gen_golden.py).  CPU only; this is what makes the oracle a trustworthy checker for the HIP engine."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import E2E_REAL, E2E_TINY, Fixture
+from oracle import flow_oracle as O
+
+
+def _batch(fx, dtype):
+    return fx.t("extract_0", dtype), fx.t("extract_1", dtype), fx.t("extra", dtype)
+
+
+@pytest.mark.parametrize("name", E2E_REAL + E2E_TINY)
+def test_forward_fp64_matches_reference(name):
+    fx = Fixture(name)
+    cfg = fx.derived_cfg()
+    sd_flow, sd_emb = fx.state_dicts(torch.float64)
+    e0, e1, ex = _batch(fx, torch.float64)
+    with torch.no_grad():
+        emb = O.dgcnn_embed(cfg, sd_emb, e0)
+        np.testing.assert_allclose(emb.numpy(), fx.a["emb_f64"], rtol=1e-9, atol=1e-9)
+        loss, lp, bpd = O.inner_loop(cfg, sd_flow, sd_emb, (e0, e1, ex), fx.eps(torch.float64))
+    np.testing.assert_allclose(lp.numpy(), fx.a["log_prob_f64"], rtol=1e-9, atol=1e-8)
+    assert abs(float(bpd) - float(fx.a["bpd_f64"])) < 1e-10
+    assert abs(float(loss) - float(fx.a["loss_f64"])) < 1e-9
+
+
+@pytest.mark.parametrize("name", E2E_REAL + E2E_TINY)
+def test_per_transform_records_fp64(name):
+    fx = Fixture(name)
+    cfg = fx.derived_cfg()
+    sd_flow, sd_emb = fx.state_dicts(torch.float64)
+    e0, e1, ex = _batch(fx, torch.float64)
+    rec = []
+    with torch.no_grad():
+        emb = O.dgcnn_embed(cfg, sd_emb, e0)
+        if emb.dim() == 2:
+            emb = emb[:, None, :].expand(-1, e1.shape[1], -1)
+        extra = None if ex is None else ex[:, None, :].expand(-1, e1.shape[1], -1)
+        O.flow_log_prob(cfg, sd_flow, e1, emb, extra, fx.eps(torch.float64), record=rec)
+    ldj = torch.stack([torch.as_tensor(r[1]).expand(e1.shape[:2]) for r in rec]).numpy()
+    np.testing.assert_allclose(ldj, fx.a["ldj_f64"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(rec[-1][0][:, :8].numpy(), fx.a["z_last_f64"], rtol=1e-9, atol=1e-9)
+    if "z_sub_f64" in fx.a:
+        z = torch.stack([r[0][:, :8] for r in rec]).numpy()
+        np.testing.assert_allclose(z, fx.a["z_sub_f64"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", E2E_REAL + E2E_TINY)
+def test_forward_fp32_close_to_reference_fp32(name):
+    """fp32 oracle vs the reference's own fp32 run: same op sequence, so only BLAS summation order differs."""
+    fx = Fixture(name)
+    cfg = fx.derived_cfg()
+    sd_flow, sd_emb = fx.state_dicts(torch.float32)
+    with torch.no_grad():
+        _, lp, bpd = O.inner_loop(cfg, sd_flow, sd_emb, _batch(fx, torch.float32), fx.eps(torch.float32))
+    assert np.abs(lp.numpy() - fx.a["log_prob_f32"]).max() < 2e-3
+    assert abs(float(bpd) - float(fx.a["bpd_f64"])) < 1e-4          # the north-star gate, on the logged scalar
+
+
+@pytest.mark.parametrize("name", E2E_REAL + E2E_TINY)
+def test_inverse_fp64_matches_reference(name):
+    fx = Fixture(name)
+    cfg = fx.derived_cfg()
+    sd_flow, sd_emb = fx.state_dicts(torch.float64)
+    e0, _, ex = _batch(fx, torch.float64)
+    z = fx.t("sample_z", torch.float64)
+    with torch.no_grad():
+        x = O.make_sample(cfg, sd_flow, sd_emb, z, e0[:1], None if ex is None else ex[:1], fx.eps(torch.float64, "inveps"))
+    np.testing.assert_allclose(x.numpy(), fx.a["sample_x_f64"], rtol=1e-8, atol=1e-8)
+
+
+def test_spline_op_fixture():
+    z = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "op_spline.npz"))
+    x, w, h, d = (torch.from_numpy(z[k]) for k in ("x", "w", "h", "d"))
+    y, lad = O.rq_spline(x, w, h, d)
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(lad.numpy(), z["logabsdet"], rtol=1e-11, atol=1e-12)
+    xi, ladi = O.rq_spline(torch.from_numpy(z["y"]), w, h, d, inverse=True)
+    np.testing.assert_allclose(xi.numpy(), z["x_inv"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(ladi.numpy(), z["logabsdet_inv"], rtol=1e-10, atol=1e-11)
+    y32, lad32 = O.rq_spline(x.float(), w.float(), h.float(), d.float())
+    assert np.abs(y32.numpy() - z["y_f32"]).max() < 1e-5
+    assert np.abs(lad32.numpy() - z["logabsdet_f32"]).max() < 1e-4
+
+
+def test_knn_op_fixture():
+    z = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "op_knn.npz"))
+    for tag, k in (("xyzrgb", 40), ("feat64", 40)):
+        x = torch.from_numpy(z[f"{tag}_x"])                      # [B,C,M] channels-first like the reference
+        f = x.transpose(1, 2).contiguous()
+        idx = O.knn_indices(f.double(), k)
+        ref = torch.from_numpy(z[f"{tag}_idx_f64"].astype(np.int64))
+        assert (idx.sort(-1)[0] == ref.sort(-1)[0]).all()
+        idx32 = O.knn_indices(f, k)
+        ref32 = torch.from_numpy(z[f"{tag}_idx_f32"].astype(np.int64))
+        same = (idx32.sort(-1)[0] == ref32.sort(-1)[0]).all(-1)
+        margin = torch.from_numpy(z[f"{tag}_margin_f64"])
+        assert (same | (margin < 1e-5)).all()                    # only near-ties at the k-th boundary may differ
