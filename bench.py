@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward log-prob throughput ("nats/sec" = per-point log-prob values per second)
+of the FlowCompare conditional flow on synthetic 4096-point coloured pairs.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path (`inner_loop`: DGCNN context embedder -> 115-layer conditional flow -> loss/bpd) over one
+batch that is already resident in HBM.  Workload at N=1: BASELINE.json configs[1] = C2 (DGCNN + cross-attention, rational-
+quadratic spline coupling, batch 16, 4096 target + 4096 context points).  For N > 1 every rank runs the same per-GPU batch on
+its own scenes (scenes are independent: no data-path collective; weak scaling); the global loss is one scalar all-reduce.
+
+Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, HIP-event timing inside the library over the timed
+region) and `cpu_baseline` (the pinned CPU oracle timed on the host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import flowcompare_amd as fa  # noqa: E402
+from flowcompare_amd import engine  # noqa: E402
+
+# SURVEY.md §8(d) / BASELINE.md §4: algorithmic MFLOP per target point (1 MAC = 2 FLOP), by config
+ALG_MFLOP_PER_POINT = {"c1_dgcnn_global_affine": 396.0, "c2_dgcnn_attn_spline": 859.0, "c4_dgcnn_attn_extra_affine": 453.0}
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_pairs(B, n_ctx, n_tgt, seed, device):
+    """xyz ~ U(-1,1)^3, pair-centred and scaled to the joint unit sphere; rgb ~ U[0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(B, n_ctx + n_tgt, 3, generator=g) * 2 - 1
+    xyz = xyz - xyz.mean(1, keepdim=True)
+    xyz = xyz / xyz.norm(dim=-1).amax(1)[:, None, None]
+    rgb = torch.rand(B, n_ctx + n_tgt, 3, generator=g)
+    pts = torch.cat((xyz, rgb), -1)
+    extra = torch.rand(B, 1, generator=g) * 15.0
+    return pts[:, :n_ctx].contiguous().to(device), pts[:, n_ctx:].contiguous().to(device), extra.to(device), g
+
+
+def host_cores():
+    """CPU share this process may use: affinity mask, capped by the cgroup quota and by 16 (the 1-GPU box share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg, md, points, seed):
+    """The pinned CPU oracle (oracle/flow_oracle.py, fp32, eager PyTorch on the host cores) on ONE scene of the workload."""
+    from oracle import flow_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle on {cores} host threads, 1 scene x {points} points ...")
+    c = dict(cfg)
+    c["sample_size"] = points
+    sd_f = {k: v.detach().cpu() for k, v in md["flow"].state_dict().items()}
+    sd_e = {k: v.detach().cpu() for k, v in md["input_embedder"].state_dict().items()}
+    e0, e1, ex, g = synth_pairs(1, points, points, seed, "cpu")
+    eps = [torch.randn(1, points, c["latent_dim"] - c["input_dim"], generator=g)] if c["latent_dim"] > c["input_dim"] else []
+    batch = (e0, e1, ex if c["extra_z_value_context"] else None)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        _, lp, _ = O.inner_loop(c, sd_f, sd_e, batch, eps)
+        dt = time.perf_counter() - t0
+    return {"value": points / dt, "unit": "nats/sec", "cores": cores, "kind": "port",
+            "sample": f"1 scene of the workload (B=1, {points} target + {points} context points, all {c['n_flow_layers']} layers, fp32), "
+                      f"{dt:.1f} s of host time"}, lp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2_dgcnn_attn_spline")
+    ap.add_argument("--batch", type=int, default=16, help="scenes per GPU")
+    ap.add_argument("--points", type=int, default=4096, help="target points = context points per scene")
+    ap.add_argument("--layers", type=int, default=None, help="override n_flow_layers (INVALID as a headline number)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-points", type=int, default=None, help="points per scene of the CPU sample (default: same as --points)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    over = {"sample_size": args.points}
+    if args.layers:
+        over["n_flow_layers"] = args.layers
+    cfg = fa.named_config(args.config, **over)
+    torch.manual_seed(0)                                  # same random-init weights on every rank
+    log(f"rank {rank}: building {args.config} ({cfg['n_flow_layers']} layers) ...")
+    md = fa.initialize_flow(cfg, device=dev, mode="test")
+    B, N = args.batch, args.points
+    e0, e1, extra, g = synth_pairs(B, N, N, 1000 + rank, dev)   # every rank owns different scenes
+    batch = (e0, e1, extra if cfg["extra_z_value_context"] else None)
+    eps = [torch.randn(B, N, cfg["latent_dim"] - cfg["input_dim"], generator=g).to(dev)]
+
+    def step():
+        loss, lp, bpd = fa.inner_loop(batch, md, cfg, eps=eps)
+        if dist is not None:                              # global mean over all ranks' scenes: the only exchange of the path
+            t = torch.stack((lp.sum(), torch.tensor(float(lp.numel()), device=dev)))
+            dist.all_reduce(t)
+            loss = -(t[0] / t[1])
+            bpd = loss * math.log2(math.e) / cfg["input_dim"]
+        return loss, lp, bpd
+
+    t_build = time.perf_counter()
+    md["input_embedder"]._engine() if hasattr(md["input_embedder"], "_engine") else None
+    md["flow"]._engine()                                  # weight folding / packing / upload (one-time, not timed)
+    log(f"rank {rank}: engine packed in {time.perf_counter() - t_build:.1f} s; warmup ...")
+    for i in range(args.warmup):
+        loss, lp, bpd = step()
+        torch.cuda.synchronize()
+        log(f"rank {rank}: warmup step {i} done")
+
+    engine.profile_reset()
+    engine.profile_enable(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, lp, bpd = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    engine.profile_enable(False)
+    prof = engine.profile_report()
+    log(f"rank {rank}: {args.steps} timed steps in {dt:.3f} s")
+    if dist is not None:
+        t = torch.tensor(dt, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    if rank == 0:
+        total_pts = world * B * N * args.steps
+        value = total_pts / dt
+        tot_ms = sum(p["ms"] for p in prof) or 1.0
+        prof.sort(key=lambda p: -p["ms"])
+        dom = prof[0]
+        per_launch_ms = dom["ms"] / dom["launches"]
+        if dom["flops"] > 0:
+            achieved = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None}
+        else:
+            achieved = dom["bytes"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+        roof.update({"avg_launch_ms": per_launch_ms, "launches": dom["launches"], "share_of_gpu_time": dom["ms"] / tot_ms,
+                     "peak_source": "MI355X_MICROARCH.md: fp32-input MFMA 157.3 TFLOP/s dense (v_mfma_f32_32x32x2_f32)",
+                     "flops_counted": "useful multiply-adds of the launches (padding excluded), HIP events on the launch stream"})
+        alg = ALG_MFLOP_PER_POINT.get(args.config)
+        out = {
+            "metric": "nats/sec (forward log-prob) on 4096-pt coloured pairs", "value": value, "unit": "nats/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: batch {B} scenes/GPU x {N} target + {N} context points, "
+                                   f"{cfg['n_flow_layers']} flow layers ({cfg['flow_type']}), embedder {cfg['input_embedder']}",
+                       "global_batch": world * B, "points_per_scene": N, "parallelism": f"scene-sharded x{world}, no data-path collective"},
+            "mean_nats": float(-loss), "bpd": float(bpd),
+            "job_algorithmic_tflops": None if alg is None or args.layers else alg * 1e6 * value / 1e12,
+            "roofline": roof,
+            "kernels": [{"kernel": p["kernel"], "launches": p["launches"], "ms_per_step": p["ms"] / args.steps,
+                         "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] else None,
+                         "gbs": (p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["bytes"] else None} for p in prof[:8]],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, _ = cpu_baseline(cfg, md, args.cpu_points or N, 1000)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

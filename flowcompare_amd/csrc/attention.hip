@@ -12,6 +12,7 @@
 //     (r&3)+8(r>>2)+4h of step r), with B = V[key][d] read row-wise from LDS (conflict-free ds_read_b32).
 // No LDS round trip for P, no transposed V image.
 #include "common.h"
+#include <cstdio>
 
 namespace fc {
 
@@ -186,6 +187,9 @@ static void launch_attn_dh(const AttnParams& p, int B, hipStream_t s) {
         FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
+    char name[64];
+    snprintf(name, sizeof name, "void fc::attn_kernel<%d>(fc::AttnParams)", DH);
+    ProfScope ps(name, 4.0 * B * (double)p.N * (double)p.M * DH, 0.0, s);
     hipLaunchKernelGGL(kern, dim3((p.N + 127) / 128, B), dim3(256), lds, s, p);
     FC_HIP(hipGetLastError());
 }

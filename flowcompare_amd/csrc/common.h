@@ -32,6 +32,19 @@ inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
 constexpr int ROW_PAD = 256;   // row counts of every workspace matrix are padded to this (largest GEMM BM)
 constexpr int COL_PAD = 32;    // feature widths are padded to this (GEMM BK / MFMA tile)
 
+// ---------------------------------------------------------------- in-library kernel timing (fc_profile_*)
+// When enabled every launch is bracketed by HIP events ON THE LAUNCH STREAM; the report aggregates, per kernel
+// name (as rocprofv3 prints it), launches, total milliseconds and the useful FLOPs / algorithmic bytes the launches
+// processed.  bench.py derives its `roofline` object from this over the timed region.
+bool prof_enabled();
+struct ProfScope {
+    bool on;
+    hipStream_t s;
+    int slot = -1;
+    ProfScope(const char* name, double flops, double bytes, hipStream_t stream);
+    ~ProfScope();
+};
+
 // ---------------------------------------------------------------- device memory owned by a handle
 struct DeviceArena {
     std::vector<void*> blocks;
@@ -65,6 +78,7 @@ struct PackedLinear {
     int K_pad = 0;             // multiple of 32 (sum of segment widths)
     int seg_k[3] = {0, 0, 0};  // padded K of each A segment
     int nseg = 0;
+    int n_true = 0, k_true = 0;  // un-padded extents (useful-FLOP accounting of the profiler)
 };
 
 // A operand segment: rows x seg_k floats starting at ptr with row pitch lda
@@ -88,6 +102,7 @@ struct GemmEpi {
     const float* eps = nullptr; int d_in = 0, d1 = 0, d1_pad = 0;   // AUGMENT: latent index = d_in + q ; x1|x2 split
     float clamp = 0.f;         // AUGMENT/CIF: std clamp (0 = none)
     int rows_valid = 0;        // rows that exist in user-visible outputs
+    double flops_hint = 0.0;   // filled by launch_gemm for the profiler
 };
 
 void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const GemmEpi& e, int epi_kind, hipStream_t s);

@@ -143,7 +143,7 @@ static void dgcnn_forward(fc_dgcnn& e, const float* pts, float* out, int B, int 
         in = {w.pool, 1024};
         rows = B; rows_pad = w.R_pad;
     }
-    const int cur = run_mlp_hidden_generic(e.mlp, &in, nullptr, FC_ACT_GELU, w.h, e.H_pad, rows_pad, s);
+    const int cur = run_mlp_hidden_generic(e.mlp, &in, nullptr, FC_ACT_GELU, w.h, e.H_pad, rows_pad, s, rows);
     GemmEpi g{};
     g.C = w.otmp; g.ldc = e.E_pad;
     ASeg a{w.h[cur], e.H_pad};

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <cstring>
 
 #include "hostpack.h"
 
@@ -333,7 +334,7 @@ static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t by
 }
 
 static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_segs, const float* rowscal, FlowWs& w, int rows, hipStream_t s) {
-    return run_mlp_hidden_generic(m, in_segs, rowscal, f.cfg.nonlinearity, w.h, std::max(f.d.H_pad, 32), rows, s);
+    return run_mlp_hidden_generic(m, in_segs, rowscal, f.cfg.nonlinearity, w.h, std::max(f.d.H_pad, 32), rows, s, w.P);
 }
 
 // pre-conditioner: pre-MLP -> LayerNorm -> q -> attention; result in w.a  (models/cif_block.py:14-20 / augmenter.py:15-16)
@@ -344,12 +345,12 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
     int o = 0;
     while (o == cur) ++o;
     GemmEpi e{};
-    e.act = FC_ACT_NONE; e.C = w.h[o]; e.ldc = ldh;
+    e.act = FC_ACT_NONE; e.C = w.h[o]; e.ldc = ldh; e.rows_valid = w.P;
     ASeg a{w.h[cur], ldh};
     launch_gemm(pre.out_layer, &a, w.P_pad, e, EPI_LINEAR, s);
     launch_layernorm(w.h[o], ldh, d.A_in, w.P, s);
     GemmEpi eq{};
-    eq.act = FC_ACT_NONE; eq.C = w.q; eq.ldc = d.I_pad;
+    eq.act = FC_ACT_NONE; eq.C = w.q; eq.ldc = d.I_pad; eq.rows_valid = w.P;
     ASeg aq{w.h[o], ldh};
     launch_gemm(at.q, &aq, w.P_pad, eq, EPI_LINEAR, s);
     launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad, s);
@@ -373,7 +374,7 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
     if (d.X) { launch_repeat_extra(extra, d.X, w.rowscal, B, N, s); rowscal = w.rowscal; }
     if (f.n_attn) {
         GemmEpi e{};
-        e.C = w.kv; e.ldc = w.ldkv;
+        e.C = w.kv; e.ldc = w.ldkv; e.rows_valid = w.Pc;
         ASeg a{w.ctxp, d.E_pad};
         launch_gemm(f.kv_all, &a, w.Pc_pad, e, EPI_LINEAR, s);
     }
@@ -417,13 +418,13 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
             launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_AFFINE, s);
         } else {
             GemmEpi e{};
-            e.C = w.spl; e.ldc = d.ldp;
+            e.C = w.spl; e.ldc = d.ldp; e.rows_valid = w.P;
             launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_LINEAR, s);
             launch_spline(w.spl, d.ldp, xc, d.ldx, d.d1_pad, d.d2, c.num_bins_spline, logprob, w.P, 0, s);
         }
         if (b.has_lin) {
             GemmEpi e{};
-            e.C = xn; e.ldc = d.ldx;
+            e.C = xn; e.ldc = d.ldx; e.rows_valid = w.P;
             ASeg ax{xc, d.ldx};
             launch_gemm(b.lin, &ax, w.P_pad, e, EPI_LINEAR, s);
             std::swap(xc, xn);
@@ -435,7 +436,7 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
 }  // namespace fc
 
 // ================================================================== C ABI
-namespace fc { const char* get_last_error(); }
+namespace fc { const char* get_last_error(); void prof_set(bool); void prof_reset(); std::string prof_report_json(); }
 
 #define FC_API_BEGIN try {
 #define FC_API_END                                                    \
@@ -448,6 +449,16 @@ extern "C" {
 
 int fc_abi_version(void) { return FC_ABI_VERSION; }
 const char* fc_last_error(void) { return fc::get_last_error(); }
+
+int fc_profile_enable(int32_t on) { fc::prof_set(on != 0); return FC_OK; }
+int fc_profile_reset(void) { fc::prof_reset(); return FC_OK; }
+int fc_profile_report(char* buf, size_t cap) {
+    FC_API_BEGIN
+    const std::string r = fc::prof_report_json();
+    if (!buf || cap < r.size() + 1) throw fc::Error(FC_ERR_INVALID, "fc_profile_report: buffer too small");
+    memcpy(buf, r.c_str(), r.size() + 1);
+    FC_API_END
+}
 
 int fc_flow_create(const fc_flow_config* cfg, const fc_tensor* tensors, int32_t n_tensors, fc_flow** out) {
     FC_API_BEGIN

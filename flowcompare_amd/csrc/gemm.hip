@@ -14,6 +14,7 @@
 // Global -> LDS goes through registers (prefetch of tile t+1 is issued before the MFMAs of tile t, written
 // after them): one barrier per 32-deep K tile.
 #include "common.h"
+#include <cstdio>
 
 namespace fc {
 
@@ -248,11 +249,14 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
     }
     GemmParams q = p;
     q.nbn = (p.N_pad + BN - 1) / BN;
+    char name[96];
+    snprintf(name, sizeof name, "void fc::gemm_f32_kernel<%d, %d, %d, %d, %d>(fc::GemmParams)", BM, BN, WM, WN, EPI);
+    ProfScope ps(name, p.e.flops_hint, 0.0, s);
     hipLaunchKernelGGL(kern, dim3(q.nbm * q.nbn), dim3(256), lds, s, q);
     FC_HIP(hipGetLastError());
 }
 
-void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const GemmEpi& e, int epi_kind, hipStream_t s) {
+void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const GemmEpi& e_in, int epi_kind, hipStream_t s) {
     if (rows_alloc % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "launch_gemm: rows must be padded to ROW_PAD");
     if (L.K_pad % 32 != 0 || L.N_pad % 32 != 0 || L.nseg < 1 || L.nseg > 3) throw Error(FC_ERR_INVALID, "launch_gemm: bad packing");
     GemmParams p{};
@@ -267,6 +271,9 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     }
     if (kt * 32 != L.K_pad) throw Error(FC_ERR_INVALID, "launch_gemm: segment widths do not add up to K_pad");
     p.KT = kt;
+    GemmEpi e = e_in;
+    e.flops_hint = 2.0 * (double)(e.rows_valid > 0 ? e.rows_valid : rows_alloc) * (double)(L.n_true ? L.n_true : L.N_pad) *
+                   (double)(L.k_true ? L.k_true : L.K_pad);
     p.W = L.W; p.K_pad = L.K_pad; p.bias = L.bias; p.colvec = L.colvec; p.N_pad = L.N_pad;
     p.e = e;
     if (epi_kind == EPI_LINEAR) {

@@ -3,12 +3,74 @@
 
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
 
 namespace fc {
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& m) { g_last_error = m; }
 const char* get_last_error() { return g_last_error.c_str(); }
+
+// ---------------------------------------------------------------- profiler
+namespace {
+struct ProfRec { hipEvent_t a, b; int name; double flops, bytes; };
+struct ProfState {
+    bool on = false;
+    std::vector<std::string> names;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    int name_id(const char* n) {
+        for (size_t i = 0; i < names.size(); ++i) if (names[i] == n) return (int)i;
+        names.push_back(n);
+        return (int)names.size() - 1;
+    }
+    hipEvent_t ev() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) throw Error(FC_ERR_HIP, "hipEventCreate failed");
+        return e;
+    }
+};
+ProfState g_prof;
+}  // namespace
+bool prof_enabled() { return g_prof.on; }
+ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : on(g_prof.on), s(stream) {
+    if (!on) return;
+    ProfRec r{g_prof.ev(), g_prof.ev(), g_prof.name_id(name), flops, bytes};
+    (void)hipEventRecord(r.a, s);
+    g_prof.recs.push_back(r);
+    slot = (int)g_prof.recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (on && slot >= 0) (void)hipEventRecord(g_prof.recs[slot].b, s);
+}
+void prof_set(bool on) { g_prof.on = on; }
+void prof_reset() {
+    for (auto& r : g_prof.recs) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }
+    g_prof.recs.clear();
+}
+std::string prof_report_json() {
+    struct Agg { long long n = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::vector<Agg> agg(g_prof.names.size());
+    for (auto& r : g_prof.recs) {
+        FC_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        FC_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        Agg& a = agg[r.name];
+        a.n += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    }
+    std::string out = "[";
+    bool first = true;
+    for (size_t i = 0; i < agg.size(); ++i) {
+        if (!agg[i].n) continue;
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s{\"kernel\": \"%s\", \"launches\": %lld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 first ? "" : ", ", g_prof.names[i].c_str(), agg[i].n, agg[i].ms, agg[i].flops, agg[i].bytes);
+        out += buf;
+        first = false;
+    }
+    return out + "]";
+}
 
 // ---------------------------------------------------------------- arena
 float* DeviceArena::alloc_floats(size_t n) {
@@ -207,6 +269,8 @@ PackedLinear pack_linear(DeviceArena& arena, const MatD& W, const VecD& bias, co
         if (!bias.empty()) b[n] = (float)bias[sn];
         if (!colvec.empty()) cv[n] = (float)colvec[sn];
     }
+    for (int n : nmap) L.n_true += n >= 0;
+    for (int k : kmap) L.k_true += k >= 0;
     L.W = arena.upload(w);
     L.bias = arena.upload(b);
     L.colvec = colvec.empty() ? nullptr : arena.upload(cv);
@@ -236,9 +300,9 @@ void pack_mlp_mid(DeviceArena& arena, const WeightTable& wt, const std::string& 
     if (w_out.shape.size() != 2 || w_out.shape[1] != out.sizes.back()) throw Error(FC_ERR_SHAPE, prefix + ".out_layer.weight: input width mismatch");
 }
 int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float* rowscal, int act, float* const h[3], int ldh, int rows,
-                           hipStream_t s) {
+                           hipStream_t s, int rows_valid) {
     GemmEpi e{};
-    e.act = act; e.C = h[0]; e.ldc = ldh; e.rowscal = rowscal;
+    e.act = act; e.C = h[0]; e.ldc = ldh; e.rowscal = rowscal; e.rows_valid = rows_valid;
     launch_gemm(m.in_layer, in_segs, rows, e, EPI_LINEAR, s);
     int cur = 0, keep = -1;
     for (size_t i = 0; i < m.mid.size(); ++i) {
@@ -246,7 +310,7 @@ int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float*
         int nxt = 0;
         while (nxt == cur || nxt == keep) ++nxt;
         GemmEpi g{};
-        g.act = act; g.C = h[nxt]; g.ldc = ldh;
+        g.act = act; g.C = h[nxt]; g.ldc = ldh; g.rows_valid = rows_valid;
         if (i % 2 == 1) { g.residual = h[keep]; g.ldr = ldh; }
         ASeg a{h[cur], ldh};
         launch_gemm(m.mid[i], &a, rows, g, EPI_LINEAR, s);

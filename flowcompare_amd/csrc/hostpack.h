@@ -49,6 +49,6 @@ int max_hidden_pad(const PackedMLP& m);
 // odd: x = act(keep + W x)) over three rotating activation buffers h[0..2] of pitch ldh; returns the buffer index holding the
 // last hidden activation (the caller applies out_layer with the epilogue it needs).
 int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float* rowscal, int act, float* const h[3], int ldh, int rows,
-                           hipStream_t s);
+                           hipStream_t s, int rows_valid = 0);
 
 }  // namespace fc

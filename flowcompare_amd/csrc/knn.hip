@@ -165,6 +165,7 @@ void launch_knn(const float* f, int ldf, int C, int32_t* idx, int B, int M, int 
         FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
+    ProfScope ps("fc::knn_kernel(float const*, int, int, int*, int, int, int)", 2.0 * B * (double)M * M * C, 4.0 * B * (double)M * (C + k), s);
     hipLaunchKernelGGL(knn_kernel, dim3((M + 15) / 16, B), dim3(256), lds, s, f, ldf, Cp, idx, M, m_stride_rows, k);
     FC_HIP(hipGetLastError());
 }

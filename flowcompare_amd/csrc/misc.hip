@@ -28,6 +28,7 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, int src_ld, int 
 void launch_pack_rows(const float* src, int src_ld, int src_cols, float* dst, int dst_ld, int dst_col0, int zero_to, int rows,
                       hipStream_t s) {
     if (rows <= 0) return;
+    ProfScope ps("fc::pack_rows_kernel", 0.0, 4.0 * rows * ((double)src_cols + zero_to), s);
     hipLaunchKernelGGL(pack_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, src_ld, src_cols, dst, dst_ld, dst_col0, zero_to, rows);
     FC_HIP(hipGetLastError());
 }
@@ -41,6 +42,7 @@ void launch_fill(float* p, float v, size_t n, hipStream_t s) {
     if (!n) return;
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    ProfScope ps("fc::fill_kernel", 0.0, 4.0 * n, s);
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, v, n);
     FC_HIP(hipGetLastError());
 }
@@ -86,6 +88,7 @@ __global__ void layernorm_kernel(float* h, int ld, int width, int rows) {
 }
 void launch_layernorm(float* h, int ld, int width, int rows, hipStream_t s) {
     if (width > 1024) throw Error(FC_ERR_UNSUPPORTED, "layernorm: width > 1024");
+    ProfScope ps("fc::layernorm_kernel(float*, int, int, int)", 0.0, 8.0 * rows * width, s);
     hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, ld, width, rows);
     FC_HIP(hipGetLastError());
 }
@@ -109,6 +112,7 @@ __global__ void base_density_kernel(const float* __restrict__ x, int ldx, int d1
 }
 void launch_base_density(const float* x, int ldx, int d1, int d1_pad, int d2, float* logprob, float log_const, float* z_out, int D,
                          int rows, hipStream_t s) {
+    ProfScope ps("fc::base_density_kernel", 0.0, 4.0 * rows * (D + 2.0 + (z_out ? D : 0)), s);
     hipLaunchKernelGGL(base_density_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, d1, d1_pad, d2, logprob, log_const, z_out, D, rows);
     FC_HIP(hipGetLastError());
 }
@@ -252,6 +256,8 @@ void launch_spline(const float* params, int ldp, float* xbuf, int ldx, int x2_co
         FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spline_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
+    ProfScope ps("fc::spline_rows_kernel(float const*, int, float*, int, int, int, int, float*, int, int)", 0.0,
+                 4.0 * rows * ((double)npar + 2.0 * d2 + 2.0), s);
     hipLaunchKernelGGL(spline_rows_kernel, dim3((rows + 3) / 4), dim3(256), lds, s, params, ldp, xbuf, ldx, x2_col0, d2, K, logprob, rows, inverse);
     FC_HIP(hipGetLastError());
 }
@@ -292,6 +298,7 @@ __global__ void gather_max_kernel(const float* __restrict__ uv, int lduv, int c_
 void launch_gather_max(const float* uv, int lduv, int c_out, const int32_t* idx, int k, float* out, int ldo, int out_col0, int B, int M,
                        int m_stride_rows, hipStream_t s) {
     const int total = B * M;
+    ProfScope ps("fc::gather_max_kernel", 0.0, 4.0 * total * ((double)k * c_out + 2.0 * c_out + k), s);
     hipLaunchKernelGGL(gather_max_kernel, dim3((total + 3) / 4), dim3(256), 0, s, uv, lduv, c_out, idx, k, out, ldo, out_col0, M, m_stride_rows, total);
     FC_HIP(hipGetLastError());
 }

@@ -24,6 +24,7 @@ EXPORTS = [
     "fc_flow_create", "fc_flow_destroy", "fc_flow_workspace_bytes", "fc_flow_noise_count", "fc_flow_noise_width",
     "fc_flow_logprob_f32", "fc_flow_inverse_f32",
     "fc_dgcnn_create", "fc_dgcnn_destroy", "fc_dgcnn_out_dim", "fc_dgcnn_workspace_bytes", "fc_dgcnn_embed_f32",
+    "fc_profile_enable", "fc_profile_reset", "fc_profile_report",
     "fc_op_linear_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
 ]
 
@@ -280,3 +281,20 @@ def op_rqspline(x, params, num_bins, inverse=False):
     with torch.cuda.device(x.device):
         _check(lib().fc_op_rqspline_f32(_ptr(x), _ptr(params), _ptr(y), _ptr(lad), ctypes.c_int64(n), num_bins, int(inverse), _stream()))
     return y, lad
+
+
+# ---------------------------------------------------------------- in-library kernel timing
+def profile_enable(on=True):
+    _check(lib().fc_profile_enable(int(bool(on))))
+
+
+def profile_reset():
+    _check(lib().fc_profile_reset())
+
+
+def profile_report():
+    """[{kernel, launches, ms, flops, bytes}] accumulated since the last reset (HIP events on the launch stream)."""
+    import json
+    buf = ctypes.create_string_buffer(1 << 16)
+    _check(lib().fc_profile_report(buf, ctypes.c_size_t(len(buf))))
+    return json.loads(buf.value.decode())

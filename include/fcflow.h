@@ -122,6 +122,14 @@ int fc_dgcnn_workspace_bytes(const fc_dgcnn* emb, int32_t B, int32_t M, size_t* 
 int fc_dgcnn_embed_f32(fc_dgcnn* emb, const float* pts, float* out, int32_t B, int32_t M,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- in-library kernel timing (used by bench.py for the roofline object) --------------------- */
+/* When enabled, every kernel launch of this library is bracketed by HIP events on its launch stream.
+ * fc_profile_report writes a JSON array [{"kernel", "launches", "ms", "flops", "bytes"}, ...] (kernel names as
+ * rocprofv3 prints them; flops = useful multiply-add FLOPs excluding padding, bytes = algorithmic HBM bytes). */
+int fc_profile_enable(int32_t on);
+int fc_profile_reset(void);
+int fc_profile_report(char* buf, size_t cap);
+
 /* ---- single operators (same kernels as above; exported for unit-level parity tests) ---------- */
 
 /* y[rows,N] = act( x[rows,K] @ W[N,K]^T + bias + residual ), torch.nn.functional.linear semantics

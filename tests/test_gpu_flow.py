@@ -1,0 +1,119 @@
+"""End-to-end parity of the HIP engine behind the reference's module API (initialize_flow / inner_loop) against
+(a) golden vectors produced by running the reference in fp64 and fp32 and (b) the pinned CPU oracle.
+
+Tolerances (north_star: nats within 1e-4): the reference's own fp32 forward differs from its fp64
+forward by up to ~8e-4 nats per point on these fixtures, so the 1e-4 gate is applied to the logged scalar
+(bpd = mean nats * log2(e) / 6, what the reference logs as 'nats') against the fp64 golden, and per-point log-probs
+must stay within PER_POINT_TOL of the fp64 golden (same order as the reference's own fp32 noise)."""
+import numpy as np
+import pytest
+import torch
+
+import flowcompare_amd as fa
+from conftest import Fixture
+from oracle import flow_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BPD_TOL = 1e-4
+PER_POINT_TOL = 2e-3
+MEAN_ABS_TOL = 3e-4
+
+SUPPORTED = ["e2e_dulcet_L3", "e2e_c1_global_L2", "e2e_spline_L2", "e2e_affine_exp_L2", "e2e_tiny_affine", "e2e_tiny_spline_relu",
+             "e2e_tiny_random_permute", "e2e_tiny_FullCombiner", "e2e_tiny_ExponentialCombiner", "e2e_tiny_global_extra",
+             "e2e_tiny_identity_aug"]
+
+
+def _build(fx):
+    cfg = dict(fx.cfg)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    sd_flow, sd_emb = fx.state_dicts()
+    fa.load_flow({"flow": sd_flow, "input_embedder": sd_emb}, md)
+    return cfg, md
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_inner_loop_matches_reference_golden(name):
+    fx = Fixture(name)
+    cfg, md = _build(fx)
+    batch = tuple(None if t is None else t.to(DEV) for t in (fx.t("extract_0"), fx.t("extract_1"), fx.t("extra")))
+    eps = [e.to(DEV) for e in fx.eps()]
+    loss, lp, bpd = fa.inner_loop(batch, md, cfg, eps=eps)
+    lp = lp.cpu().double().numpy()
+    d64 = np.abs(lp - fx.a["log_prob_f64"])
+    print(f"{name}: vs fp64 golden max {d64.max():.2e} mean {d64.mean():.2e}; ref fp32 vs fp64 max "
+          f"{np.abs(fx.a['log_prob_f32'] - fx.a['log_prob_f64']).max():.2e}; bpd diff {abs(float(bpd) - float(fx.a['bpd_f64'])):.2e}")
+    assert np.isfinite(lp).all()
+    assert abs(float(bpd) - float(fx.a["bpd_f64"])) < BPD_TOL
+    assert abs(float(loss) - float(fx.a["loss_f64"])) < 6 * BPD_TOL / np.log2(np.e) * 1.0 + 1e-4
+    assert d64.max() < PER_POINT_TOL and d64.mean() < MEAN_ABS_TOL
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_embedder_and_latent_match_reference_golden(name):
+    fx = Fixture(name)
+    cfg, md = _build(fx)
+    e0 = fx.t("extract_0").to(DEV)
+    emb = md["input_embedder"](e0[:, :, :6])
+    ref = fx.a["emb_f64"]
+    d = np.abs(emb.cpu().double().numpy() - ref)
+    print(f"{name}: embedder max {d.max():.2e} mean {d.mean():.2e}")
+    assert d.mean() < 1e-5 and np.quantile(d, 0.99) < 1e-4        # k-NN near-ties may move a few points (max-pool is discontinuous)
+    # latent after the last transform, from the engine's diagnostic output
+    ctx = torch.from_numpy(ref).float().to(DEV)
+    if ctx.dim() == 2:
+        ctx = ctx[:, None, :].expand(-1, fx.meta["N"], -1)
+    extra = fx.t("extra")
+    extra = None if extra is None else extra.to(DEV)[:, None, :].expand(-1, fx.meta["N"], -1)
+    lp, z = md["flow"]._engine().log_prob(fx.t("extract_1").to(DEV), ctx, extra, [e.to(DEV) for e in fx.eps()], return_latent=True)
+    dz = np.abs(z[:, :8].cpu().double().numpy() - fx.a["z_last_f64"])
+    print(f"{name}: latent max {dz.max():.2e}")
+    assert dz.max() < 5e-4
+    assert np.abs(lp.cpu().double().numpy() - fx.a["log_prob_f64"]).max() < PER_POINT_TOL
+
+
+def test_matches_oracle_on_fresh_seeded_inputs():
+    """HIP path vs the pinned oracle on inputs no fixture contains (module-initialised weights, torch RNG)."""
+    cfg = fa.named_config("c4_dgcnn_attn_extra_affine", n_flow_layers=4, sample_size=200)
+    torch.manual_seed(3)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    g = torch.Generator().manual_seed(4)
+    B, N, M = 3, 200, 333
+    e0, e1, ex = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g), torch.rand(B, 1, generator=g) * 15
+    eps = [torch.randn(B, N, 294, generator=g)]
+    loss, lp, bpd = fa.inner_loop((e0.to(DEV), e1.to(DEV), ex.to(DEV)), md, cfg, eps=[e.to(DEV) for e in eps])
+    sd_f = {k: v.cpu().double() for k, v in md["flow"].state_dict().items()}
+    sd_e = {k: v.cpu().double() for k, v in md["input_embedder"].state_dict().items()}
+    with torch.no_grad():
+        _, lp_o, bpd_o = O.inner_loop(cfg, sd_f, sd_e, (e0.double(), e1.double(), ex.double()), [e.double() for e in eps])
+    d = (lp.cpu().double() - lp_o).abs()
+    print(f"fresh inputs: max {d.max():.2e} mean {d.mean():.2e} bpd diff {abs(float(bpd) - float(bpd_o)):.2e}")
+    assert abs(float(bpd) - float(bpd_o)) < BPD_TOL and d.max() < PER_POINT_TOL
+
+
+def test_scene_independence_and_determinism():
+    """Scenes are independent: running a sub-batch gives bit-identical log-probs; two runs are bit-identical."""
+    fx = Fixture("e2e_dulcet_L3")
+    cfg, md = _build(fx)
+    batch = tuple(t.to(DEV) for t in (fx.t("extract_0"), fx.t("extract_1"), fx.t("extra")))
+    eps = [e.to(DEV) for e in fx.eps()]
+    _, lp1, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+    _, lp2, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+    assert torch.equal(lp1, lp2)
+    _, lp_b1, _ = fa.inner_loop(tuple(t[1:2] for t in batch), md, cfg, eps=[e[1:2] for e in eps])
+    assert torch.equal(lp_b1[0], lp1[1])
+
+
+def test_unsupported_and_bad_arguments_fail_loudly():
+    fx = Fixture("e2e_tiny_cif")
+    cfg = dict(fx.cfg)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    x = fx.t("extract_1").to(DEV)
+    with pytest.raises(RuntimeError, match="CIFblock"):
+        md["flow"].log_prob(x, context=torch.zeros(2, 24, 10, device=DEV))
+    fx = Fixture("e2e_tiny_affine")
+    cfg, md = _build(fx)
+    with pytest.raises(RuntimeError, match="extra"):
+        md["flow"].log_prob(fx.t("extract_1").to(DEV), context=torch.zeros(3, 24, 10, device=DEV), extra_context=None)
+    with pytest.raises(RuntimeError, match="n_neighbors|fewer"):
+        md["input_embedder"](torch.rand(1, 5, 6, device=DEV))

@@ -1,0 +1,114 @@
+"""Unit-level parity of the HIP kernels, called through the C ABI (fc_op_*), against fp64 math on the host."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from flowcompare_amd import engine
+from oracle import flow_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+@pytest.mark.parametrize("rows,N,K,act,res", [
+    (1000, 512, 512, "gelu", True), (300, 256, 150, "gelu", False), (257, 300, 512, "none", False), (64, 64, 256, "none", False),
+    (513, 3750, 512, "none", False), (100, 128, 12, "lrelu", False), (37, 24, 215, "relu", True), (129, 588, 96, "elu", False),
+    (2048, 320, 320, "none", False), (1, 1, 1, "gelu", False),
+])
+def test_linear_matches_fp64(rows, N, K, act, res):
+    """fp32 MFMA GEMM + fused epilogue vs fp64 F.linear; tolerance = fp32 fmaf-chain error bound ~ K * 2^-23 * sum|a b|."""
+    x, W, b = _rand(rows, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3, scale=0.1)
+    r = _rand(rows, N, seed=4) if res else None
+    y = engine.op_linear(x.to(DEV), W.to(DEV), b.to(DEV), None if r is None else r.to(DEV), act).cpu().double()
+    ref = torch.nn.functional.linear(x.double(), W.double(), b.double())
+    if res:
+        ref = ref + r.double()
+    ref = {"none": lambda t: t, "gelu": torch.nn.functional.gelu, "relu": torch.relu, "elu": torch.nn.functional.elu,
+           "lrelu": lambda t: torch.nn.functional.leaky_relu(t, 0.2)}[act](ref)
+    assert (y - ref).abs().max().item() < 2e-6 * max(1.0, K ** 0.5)
+
+
+def test_linear_is_linear_and_exact_on_integers():
+    """Integer-valued operands make every partial sum exact in fp32: the MFMA path must be bit-exact, which
+    catches any fragment-layout / k-mapping mistake (asymmetric W so a transposed store cannot pass)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-8, 9, (384, 200), generator=g).float()
+    W = torch.randint(-8, 9, (330, 200), generator=g).float()
+    y = engine.op_linear(x.to(DEV), W.to(DEV)).cpu()
+    assert torch.equal(y, x @ W.t())
+
+
+@pytest.mark.parametrize("B,N,M,D", [(2, 128, 64, 64), (3, 100, 130, 64), (1, 20, 24, 32), (2, 257, 1000, 64), (1, 64, 4096, 64), (2, 40, 70, 128)])
+def test_attention_matches_fp64(B, N, M, D):
+    q, k, v = _rand(B, N, D, seed=1, scale=2.0), _rand(B, M, D, seed=2, scale=2.0), _rand(B, M, D, seed=3)
+    scale = D ** -0.5
+    out = engine.op_attention(q.to(DEV), k.to(DEV), v.to(DEV), scale).cpu().double()
+    w = torch.softmax(q.double() @ k.double().transpose(1, 2) * scale, -1)
+    ref = w @ v.double()
+    assert (out - ref).abs().max().item() < 5e-6
+
+
+def test_attention_spiked_scores_force_rescale():
+    """One key dominates late in the sequence so the running max jumps in the LAST tile (online-softmax rescale branch)."""
+    B, N, M, D = 1, 64, 512, 64
+    q, k, v = _rand(B, N, D, seed=1), _rand(B, M, D, seed=2), _rand(B, M, D, seed=3)
+    k[0, 500] = q[0, 7] * 40.0
+    out = engine.op_attention(q.to(DEV), k.to(DEV), v.to(DEV), 1.0).cpu().double()
+    ref = torch.softmax(q.double() @ k.double().transpose(1, 2), -1) @ v.double()
+    assert (out - ref).abs().max().item() < 5e-6
+
+
+def test_knn_golden_and_ties():
+    z = np.load(os.path.join(GOLDEN, "op_knn.npz"))
+    for tag in ("xyzrgb", "feat64"):
+        x = torch.from_numpy(z[f"{tag}_x"])
+        f = x.transpose(1, 2).contiguous()
+        idx = engine.op_knn(f.to(DEV), 40).cpu().long().sort(-1)[0]
+        ref = torch.from_numpy(z[f"{tag}_idx_f64"].astype(np.int64)).sort(-1)[0]
+        same = (idx == ref).all(-1)
+        margin = torch.from_numpy(z[f"{tag}_margin_f64"])
+        assert (same | (margin < 1e-5)).all(), f"{tag}: {int((~same).sum())} rows differ beyond near-ties"
+        assert same.float().mean() > 0.99
+
+
+@pytest.mark.parametrize("B,M,C,k", [(2, 1024, 6, 40), (1, 700, 64, 40), (2, 300, 128, 40), (1, 64, 6, 64), (1, 50, 16, 1)])
+def test_knn_random_vs_fp64(B, M, C, k):
+    f = _rand(B, M, C, seed=7)
+    idx = engine.op_knn(f.to(DEV), k).cpu().long()
+    assert idx.min() >= 0 and idx.max() < M
+    assert (idx.sort(-1)[0][..., 1:] != idx.sort(-1)[0][..., :-1]).all(), "duplicate neighbours"
+    fd = f.double()
+    sq = (fd ** 2).sum(-1)
+    pd = -sq[:, None, :] + 2 * fd @ fd.transpose(1, 2) - sq[:, :, None]
+    srt = pd.sort(-1, descending=True)
+    kth = srt.values[..., k - 1]
+    got = torch.gather(pd, 2, idx)
+    assert (got >= kth[..., None] - 1e-5).all()                 # every returned neighbour is within fp32 noise of the true top-k
+    assert (idx == torch.arange(M)[None, :, None]).any(-1).all()  # self is always a neighbour
+
+
+def test_spline_golden_forward_and_inverse():
+    z = np.load(os.path.join(GOLDEN, "op_spline.npz"))
+    x, w, h, d = (torch.from_numpy(z[k]).float() for k in ("x", "w", "h", "d"))
+    params = torch.cat((w, h, d), -1)
+    y, lad = engine.op_rqspline(x.to(DEV), params.to(DEV), 8)
+    # inputs within one fp32 ulp of +-3 change side when cast to fp32: compare those against the reference's own fp32 run
+    same_side = torch.from_numpy((np.abs(z["x"]) <= 3) == (np.abs(z["x"].astype(np.float32)) <= 3))
+    assert (~same_side).sum() <= 2
+    assert np.abs(y.cpu().numpy() - z["y"])[same_side.numpy()].max() < 2e-5
+    assert np.abs(lad.cpu().numpy() - z["logabsdet"])[same_side.numpy()].max() < 2e-4
+    assert np.abs(y.cpu().numpy() - z["y_f32"]).max() < 2e-5 and np.abs(lad.cpu().numpy() - z["logabsdet_f32"]).max() < 2e-4
+    xi, ladi = engine.op_rqspline(torch.from_numpy(z["y"]).float().to(DEV), params.to(DEV), 8, inverse=True)
+    assert np.abs(xi.cpu().numpy() - z["x_inv"]).max() < 5e-5
+    assert np.abs(ladi.cpu().numpy() - z["logabsdet_inv"]).max() < 5e-4
+    # tails: identity with zero log-det, knots: +-3 inclusive
+    out = (x.abs() > 3)
+    assert torch.equal(y.cpu()[out], x[out]) and (lad.cpu()[out] == 0).all()

@@ -1,0 +1,92 @@
+"""CPU-side checks: checkpoint-name compatibility of the module mirror, config handling, the C-ABI surface
+(library loads and exports every symbol include/fcflow.h declares) and 'no silent fallback' behaviour."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import flowcompare_amd as fa
+from flowcompare_amd import engine
+from conftest import E2E_REAL, E2E_TINY, ROOT, Fixture
+
+
+@pytest.mark.parametrize("name", E2E_REAL + E2E_TINY)
+def test_state_dict_names_match_reference(name):
+    """Our containers must expose exactly the reference's checkpoint keys and shapes."""
+    fx = Fixture(name)
+    cfg = dict(fx.cfg)
+    md = fa.initialize_flow(cfg, device="cpu", mode="test")
+    for part in ("flow", "input_embedder"):
+        ours = {k: list(v.shape) for k, v in md[part].state_dict().items()}
+        assert ours == fx.sd_keys[part], f"{part}: " + str(set(ours) ^ set(fx.sd_keys[part]))
+    assert cfg["extra_context_dim"] == (1 if cfg["extra_z_value_context"] else 0)
+    assert cfg["global"] == (cfg["input_embedder"] == "DGCNNembedderGlobal")
+    assert len(md["parameters"]) == len(list(md["flow"].parameters())) + len(list(md["input_embedder"].parameters()))
+
+
+def test_load_save_roundtrip(tmp_path):
+    fx = Fixture("e2e_tiny_affine")
+    cfg = dict(fx.cfg)
+    md = fa.initialize_flow(cfg, device="cpu", mode="test")
+    sd_flow, sd_emb = fx.state_dicts()
+    fa.load_flow({"flow": sd_flow, "input_embedder": sd_emb}, md)
+    p = tmp_path / "ckpt.pt"
+    opt = torch.optim.Adam(md["parameters"], lr=1e-4)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt)
+    fa.save_flow(md, cfg, opt, sched, str(p))
+    ck = torch.load(str(p), weights_only=False)
+    assert set(ck) == {"config", "optimizer", "flow", "input_embedder", "scheduler"}
+    for k, v in sd_flow.items():
+        assert torch.equal(ck["flow"][k].float(), v.float())
+
+
+def test_named_configs_and_reference_yaml_format(tmp_path):
+    c2 = fa.named_config("c2_dgcnn_attn_spline")
+    assert c2["flow_type"] == "RationalQuadraticSplineCoupling" and c2["n_flow_layers"] == 115 and c2["latent_dim"] == 300
+    c1 = fa.named_config("c1_dgcnn_global_affine")
+    assert c1["input_embedder"] == "DGCNNembedderGlobal" and c1["input_embedding_dim"] == 124 and len(c1["hidden_dims"]) == 6
+    p = tmp_path / "wandb_style.yaml"
+    p.write_text("latent_dim:\n  desc: x\n  value: 12\nflow_type:\n  value: AffineCoupling\n")
+    c = fa.config_loader(str(p))
+    assert c["latent_dim"] == 12 and c["flow_type"] == "AffineCoupling" and c["n_neighbors"] == 40
+
+
+def test_invalid_configs_raise_like_reference():
+    base = Fixture("e2e_tiny_affine").cfg
+    for over, msg in ((dict(flow_type="Nope"), "Invalid flow type"), (dict(permuter_type="Nope"), "Invalid permuter type"),
+                      (dict(coupling_block_nonlinearity="TANH"), "Invalid coupling_block_nonlinearity"),
+                      (dict(latent_dim=4), "Latent dim < Input dim"), (dict(input_embedder="Nope"), "Invalid input embeder!"),
+                      (dict(cif_latent_dim=8), "Augment dim smaller than main latent!")):
+        cfg = dict(base); cfg.update(over)
+        with pytest.raises(Exception, match=msg):
+            fa.initialize_flow(cfg, device="cpu", mode="test")
+    cfg = dict(Fixture("e2e_tiny_cif").cfg); cfg["extra_z_value_context"] = True
+    with pytest.raises(Exception, match="Not implemented extra context with cif"):
+        fa.initialize_flow(cfg, device="cpu", mode="test")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "fcflow.h")).read()
+    declared = set(re.findall(r"\b(fc_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(engine.EXPORTS), declared ^ set(engine.EXPORTS)
+    assert os.path.exists(engine.LIB_PATH), "libfcflow.so missing: __graft_entry__.build() must have produced it"
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} not exported"
+    assert lib.fc_abi_version() == engine.ABI_VERSION
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without a HIP device; it must never route through PyTorch or the oracle."""
+    fx = Fixture("e2e_tiny_affine")
+    cfg = dict(fx.cfg)
+    md = fa.initialize_flow(cfg, device="cpu", mode="test")
+    batch = (fx.t("extract_0"), fx.t("extract_1"), fx.t("extra"))
+    with pytest.raises(RuntimeError, match="HIP device|no CPU path"):
+        fa.inner_loop(batch, md, cfg)
+    with pytest.raises(RuntimeError, match="parameter container"):
+        md["flow"].transforms[1](batch[1])
+    src = "".join(open(os.path.join(ROOT, "flowcompare_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "flowcompare_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src and "flow_oracle" not in src
