@@ -59,38 +59,34 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // ---- staging: thread t moves float4 (t % F4R) of key rows (t / F4R) + RPP*pass, for K and for V
+    // ---- staging: thread t moves float4 (t % F4R) of key rows (t / F4R) + RPP*pass, for K and for V.
+    //      Straight-line macros on plain register arrays (lambdas / conditionals here sent the tile through scratch memory).
     const int srow = tid / F4R, sc4 = (tid % F4R) * 4;
     float4 rk[PASSES], rv[PASSES];
-    const float* kb = p.k + (size_t)b * p.m_stride * p.ldk;
-    const float* vb = p.v + (size_t)b * p.m_stride * p.ldv;
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < PASSES; ++i) {
-            int key = t * 64 + srow + RPP * i;
-            key = key < p.M ? key : p.M - 1;           // clamped rows are masked to -inf below
-            rk[i] = *reinterpret_cast<const float4*>(kb + (size_t)key * p.ldk + sc4);
-            rv[i] = *reinterpret_cast<const float4*>(vb + (size_t)key * p.ldv + sc4);
-        }
-    };
-    auto lstore = [&](int stage) {
-        float* sK = smem + stage * STAGE;
-        float* sV = sK + 64 * LD;
-#pragma unroll
-        for (int i = 0; i < PASSES; ++i) {
-            *reinterpret_cast<float4*>(sK + (srow + RPP * i) * LD + sc4) = rk[i];
-            *reinterpret_cast<float4*>(sV + (srow + RPP * i) * LD + sc4) = rv[i];
-        }
-    };
+    const float* kb = p.k + (size_t)b * p.m_stride * p.ldk + sc4;
+    const float* vb = p.v + (size_t)b * p.m_stride * p.ldv + sc4;
+    float* const sKst = smem + srow * LD + sc4;
+#define FC_GLOAD(T_)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < PASSES; ++i) {                                      \
+        int key_ = (T_) * 64 + srow + RPP * i;                                                \
+        key_ = key_ < p.M ? key_ : p.M - 1; /* clamped rows are masked to -inf below */       \
+        rk[i] = *reinterpret_cast<const float4*>(kb + (size_t)key_ * p.ldk);                  \
+        rv[i] = *reinterpret_cast<const float4*>(vb + (size_t)key_ * p.ldv);                  \
+    }
+#define FC_LSTORE(ST_)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < PASSES; ++i) {                                      \
+        *reinterpret_cast<float4*>(sKst + (ST_) * STAGE + RPP * i * LD) = rk[i];              \
+        *reinterpret_cast<float4*>(sKst + (ST_) * STAGE + 64 * LD + RPP * i * LD) = rv[i];    \
+    }
 
     const int ntiles = (p.M + 63) / 64;
-    gload(0);
-    lstore(0);
+    FC_GLOAD(0)
+    FC_LSTORE(0)
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
-        const bool more = t + 1 < ntiles;
-        if (more) gload(t + 1);
+        const int tn = t + 1 < ntiles ? t + 1 : t;          // the last iteration re-loads its own tile: branch-free loop
+        FC_GLOAD(tn)
         const float* sK = smem + (t & 1) * STAGE;
         const float* sV = sK + 64 * LD;
 
@@ -160,9 +156,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                 for (int d = 0; d < DT; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[h2][r], vr[32 * d], o[d], 0, 0, 0);
             }
         }
-        if (more) lstore((t + 1) & 1);
+        FC_LSTORE((t + 1) & 1)
         __syncthreads();
     }
+#undef FC_GLOAD
+#undef FC_LSTORE
 
     // ---- normalise and store: O rows are queries (r&3)+8(r>>2)+4h of this wave, columns d = 32*dt + lane&31
 #pragma unroll

@@ -79,7 +79,21 @@ struct PackedLinear {
     int seg_k[3] = {0, 0, 0};  // padded K of each A segment
     int nseg = 0;
     int n_true = 0, k_true = 0;  // un-padded extents (useful-FLOP accounting of the profiler)
+    int n_alloc = 0;             // rows of W / bias / colvec actually allocated (zero padded to the GEMM grid)
 };
+
+// Column-tile width the GEMM launcher picks for a layer, and the row count W must be zero-padded to so that the
+// k-loop needs no bounds checks (pair = pair-packed affine / augment epilogue, always the 128x320 tile).
+inline int gemm_bn(int N_pad, bool pair) {
+    if (pair) return 320;
+    if (N_pad <= 64) return 64;
+    if (N_pad % 128 == 0 || N_pad > 320) return 128;
+    return 320;
+}
+inline int gemm_n_alloc(int N_pad) {
+    const int a = round_up(N_pad, gemm_bn(N_pad, false)), b = round_up(N_pad, 320);
+    return a > b ? a : b;
+}
 
 // A operand segment: rows x seg_k floats starting at ptr with row pitch lda
 struct ASeg { const float* ptr; int lda; };

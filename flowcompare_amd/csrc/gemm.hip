@@ -31,12 +31,41 @@ struct GemmParams {
     const float* colvec;
     int N_pad;
     int nbm, nbn;
+    int stagger;
     GemmEpi e;
 };
 
+// erf for the exact-GELU epilogue.  Own piecewise fit (profiles/micro/fit_erf.py): |x| <= 0.95: x * P5(x^2); 0.95 < |x| < 4:
+// 1 - exp(P8(|x|)) (P8 fits log erfc); |x| >= 4: +-1.  Max abs error vs fp64 erf 1.5e-7 (about one fp32 ulp of the result),
+// branch-light (both arms are short fma chains) where ocml's erff costs several times more VALU issue in the epilogue.
+__device__ __forceinline__ float fc_erf(float x) {
+    const float t = fabsf(x);
+    const float s = x * x;
+    float r = -0.0005881639663130045f;
+    r = fmaf(r, s, 0.004971958696842194f);
+    r = fmaf(r, s, -0.026752419769763947f);
+    r = fmaf(r, s, 0.11281437426805496f);
+    r = fmaf(r, s, -0.3761245906352997f);
+    r = fmaf(r, s, 1.1283791065216064f);
+    const float small = r * x;
+    float q = 1.6150449937413214e-06f;
+    q = fmaf(q, t, -4.561102105071768e-05f);
+    q = fmaf(q, t, 0.0005929505568929017f);
+    q = fmaf(q, t, -0.00474111782386899f);
+    q = fmaf(q, t, 0.026367414742708206f);
+    q = fmaf(q, t, -0.10998330265283585f);
+    q = fmaf(q, t, -0.6319313645362854f);
+    q = fmaf(q, t, -1.1301703453063965f);
+    q = fmaf(q, t, 0.00030417676316574216f);
+    float big = 1.0f - __expf(q);
+    big = t >= 4.0f ? 1.0f : big;
+    big = copysignf(big, x);
+    return t <= 0.95f ? small : big;
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
-        case FC_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case FC_ACT_GELU: return 0.5f * v * (1.0f + fc_erf(v * 0.70710678118654752440f));
         case FC_ACT_RELU: return v > 0.f ? v : 0.f;
         case FC_ACT_ELU: return v > 0.f ? v : expm1f(v);
         case FC_ACT_LRELU02: return v > 0.f ? v : 0.2f * v;
@@ -56,7 +85,7 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 
 constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -80,99 +109,150 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
     const int m0 = bm * BM, n0 = bn * BN;
     const int wave_n0 = n0 + wc * TN * 32;
-    int nvalid = (p.N_pad - wave_n0) / 32;                 // wave-uniform number of live 32-col tiles
-    nvalid = nvalid < 0 ? 0 : (nvalid > TN ? TN : nvalid);
+    const int wave_m0 = m0 + wr * TM * 32;
+    int nvalid = (p.N_pad - wave_n0) / 32;                 // wave-uniform number of live 32-col tiles (for the stores only:
+    nvalid = nvalid < 0 ? 0 : (nvalid > TN ? TN : nvalid); // W / bias are allocated zero-padded to the grid, the k-loop is branch free)
+    const GemmEpi& e = p.e;
 
+    // Two workgroups share a CU and run the same program on equal work: left alone they move in lockstep (both in the
+    // prologue, at the barrier or in the epilogue together), which leaves the matrix pipe idle while they do.  A one-off
+    // offset for the second resident set de-phases them for the rest of the launch (placement only changes speed).
+    if (p.stagger && blockIdx.x >= 256 && blockIdx.x < 512) __builtin_amdgcn_s_sleep(40);
+
+    // ---- accumulators start from the epilogue's additive terms (bias, rank-1 extra-context term, residual), so their
+    //      global loads overlap the first tile's loads instead of forming a dependent tail after the last MFMA.
+    //      Every runtime condition is hoisted OUTSIDE the unrolled element loops (a per-element "load or not" makes
+    //      hipcc branch and wait vmcnt(0) around each load).
     floatx16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+        float bv = 0.f;
+        if constexpr (EPI == EPI_LINEAR) bv = p.bias ? p.bias[wave_n0 + j * 32 + li] : 0.f;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- global -> register staging: thread t loads float4 (t&7) of rows (t>>3) + 32*i
-    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
-    float4 ra[A_F4], rb[B_F4];
-    auto gload = [&](int kt) {
-        const float* Ap = p.A[0];
-        int lda = p.lda[0], kk = kt;
-        if (kk >= p.kt[0]) {
-            kk -= p.kt[0];
-            Ap = p.A[1]; lda = p.lda[1];
-            if (kk >= p.kt[1]) { kk -= p.kt[1]; Ap = p.A[2]; lda = p.lda[2]; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = bv;
+    }
+    if constexpr (EPI == EPI_LINEAR) {
+        if (e.rowscal && p.colvec) {
+            float rs[TM][16];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rs[i][r] = e.rowscal[wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float cv = p.colvec[wave_n0 + j * 32 + li];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += rs[i][r] * cv;
+            }
         }
-        const float* a = Ap + (size_t)(m0 + lrow) * lda + kk * 32 + lc4;
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(a + (size_t)(32 * i) * lda);
-        const float* w = p.W + (size_t)(n0 + lrow) * p.K_pad + kt * 32 + lc4;
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            if (n0 + lrow + 32 * i < p.N_pad) rb[i] = *reinterpret_cast<const float4*>(w + (size_t)(32 * i) * p.K_pad);
-            else rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto lstore = [&](int stage) {
-        float* sA = smem + stage * STAGE;
-        float* sB = sA + BM * LDS_LD;
-#pragma unroll
-        for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(sA + (lrow + 32 * i) * LDS_LD + lc4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_F4; ++i) *reinterpret_cast<float4*>(sB + (lrow + 32 * i) * LDS_LD + lc4) = rb[i];
-    };
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < p.KT; ++kt) {
-        const bool more = kt + 1 < p.KT;
-        if (more) gload(kt + 1);
-        const float* sA = smem + (kt & 1) * STAGE + (wr * TM * 32 + li) * LDS_LD + 4 * lh;
-        const float* sB = smem + (kt & 1) * STAGE + BM * LDS_LD + (wc * TN * 32 + li) * LDS_LD + 4 * lh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 a[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(sA + i * 32 * LDS_LD + 8 * g);
+        if (e.residual) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (j < nvalid) {
-                    const float4 b = *reinterpret_cast<const float4*>(sB + j * 32 * LDS_LD + 8 * g);
+                    const float* rp = e.residual + (size_t)(wave_m0 + 4 * lh) * e.ldr + wave_n0 + j * 32 + li;
+                    float t[TM][16];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b.x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b.y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b.z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b.w, acc[i][j], 0, 0, 0);
-                    }
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) t[i][r] = rp[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * e.ldr];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += t[i][r];
                 }
             }
         }
-        if (more) lstore((kt + 1) & 1);
+    }
+
+    // ---- global -> register staging: thread t moves float4 (t&7) of rows (t>>3) + 32*i.  Straight-line code on plain
+    //      register arrays (no lambdas / conditionals around them: those sent the staging tile through scratch memory).
+    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+    float4 ra[A_F4], rb[B_F4];
+    const float* wbase = p.W + (size_t)(n0 + lrow) * p.K_pad + lc4;
+    const size_t wstep = (size_t)32 * p.K_pad;
+    float* const sAst = smem + lrow * LDS_LD + lc4;
+    float* const sBst = sAst + BM * LDS_LD;
+
+#define FC_GLOAD(KT_)                                                                                              \
+    {                                                                                                              \
+        const float* Ap_ = p.A[0];                                                                                 \
+        int lda_ = p.lda[0], kk_ = (KT_);                                                                          \
+        if (kk_ >= p.kt[0]) {                                                                                      \
+            kk_ -= p.kt[0]; Ap_ = p.A[1]; lda_ = p.lda[1];                                                         \
+            if (kk_ >= p.kt[1]) { kk_ -= p.kt[1]; Ap_ = p.A[2]; lda_ = p.lda[2]; }                                 \
+        }                                                                                                          \
+        const float* a_ = Ap_ + (size_t)(m0 + lrow) * lda_ + kk_ * 32 + lc4;                                       \
+        _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(32 * i) * lda_); \
+        const float* w_ = wbase + (KT_) * 32;                                                                      \
+        _Pragma("unroll") for (int i = 0; i < B_F4; ++i) rb[i] = *reinterpret_cast<const float4*>(w_ + i * wstep);  \
+    }
+#define FC_LSTORE(STAGE_)                                                                                          \
+    {                                                                                                              \
+        float* sa_ = sAst + (STAGE_) * STAGE;                                                                      \
+        float* sb_ = sBst + (STAGE_) * STAGE;                                                                      \
+        _Pragma("unroll") for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(sa_ + 32 * i * LDS_LD) = ra[i]; \
+        _Pragma("unroll") for (int i = 0; i < B_F4; ++i) *reinterpret_cast<float4*>(sb_ + 32 * i * LDS_LD) = rb[i]; \
+    }
+
+    FC_GLOAD(0)
+    FC_LSTORE(0)
+    __syncthreads();
+
+    float4 af[2][TM], bf[2][TN];
+    for (int kt = 0; kt < p.KT; ++kt) {
+        const int ktn = kt + 1 < p.KT ? kt + 1 : kt;        // last iteration re-loads its own tile: keeps the loop branch free
+        FC_GLOAD(ktn)
+        const float* sA = smem + (kt & 1) * STAGE + (wr * TM * 32 + li) * LDS_LD + 4 * lh;
+        const float* sB = smem + (kt & 1) * STAGE + BM * LDS_LD + (wc * TN * 32 + li) * LDS_LD + 4 * lh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const float4*>(sA + i * 32 * LDS_LD);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const float4*>(sB + j * 32 * LDS_LD);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cb = g & 1, nb = cb ^ 1;
+            if (g < 3) {                                   // fragments of the next 8-deep k group fly while this group's MFMAs run
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[nb][i] = *reinterpret_cast<const float4*>(sA + i * 32 * LDS_LD + 8 * (g + 1));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[nb][j] = *reinterpret_cast<const float4*>(sB + j * 32 * LDS_LD + 8 * (g + 1));
+            } else if (VAR == 2) {
+                FC_LSTORE((kt + 1) & 1)                     // next tile's LDS image is written under the last group's MFMAs
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].x, bf[cb][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].y, bf[cb][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].z, bf[cb][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][i].w, bf[cb][j].w, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (VAR != 2) FC_LSTORE((kt + 1) & 1)
         __syncthreads();
     }
+#undef FC_GLOAD
+#undef FC_LSTORE
 
     // ------------------------------------------------------------------ epilogues
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15
-    const GemmEpi& e = p.e;
-    const int wave_m0 = m0 + wr * TM * 32;
     if constexpr (EPI == EPI_LINEAR) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (j < nvalid) {
                 const int col = wave_n0 + j * 32 + li;
-                const float bv = p.bias ? p.bias[col] : 0.f;
-                const float cv = (p.colvec && e.rowscal) ? p.colvec[col] : 0.f;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        float v = acc[i][j][r] + bv;
-                        if (e.rowscal) v += e.rowscal[row] * cv;
-                        if (e.residual) v += e.residual[(size_t)row * e.ldr + col];
-                        e.C[(size_t)row * e.ldc + col] = act_apply(v, e.act);
+                        e.C[(size_t)row * e.ldc + col] = act_apply(acc[i][j][r], e.act);
                     }
                 }
             }
@@ -238,11 +318,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+int g_gemm_variant = 2, g_gemm_stagger = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+
+template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
     constexpr size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, EPI>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, EPI, VAR>;
     if (!attr_done) {
         FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
@@ -250,7 +332,7 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
     GemmParams q = p;
     q.nbn = (p.N_pad + BN - 1) / BN;
     char name[96];
-    snprintf(name, sizeof name, "void fc::gemm_f32_kernel<%d, %d, %d, %d, %d>(fc::GemmParams)", BM, BN, WM, WN, EPI);
+    snprintf(name, sizeof name, "void fc::gemm_f32_kernel<%d, %d, %d, %d, %d, %d>(fc::GemmParams)", BM, BN, WM, WN, EPI, VAR);
     ProfScope ps(name, p.e.flops_hint, 0.0, s);
     hipLaunchKernelGGL(kern, dim3(q.nbm * q.nbn), dim3(256), lds, s, q);
     FC_HIP(hipGetLastError());
@@ -270,16 +352,24 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         kt += p.kt[i];
     }
     if (kt * 32 != L.K_pad) throw Error(FC_ERR_INVALID, "launch_gemm: segment widths do not add up to K_pad");
+    if (L.n_alloc < round_up(L.N_pad, gemm_bn(L.N_pad, epi_kind != EPI_LINEAR)))
+        throw Error(FC_ERR_INVALID, "launch_gemm: W is not zero-padded to the column-tile grid (PackedLinear.n_alloc)");
     p.KT = kt;
     GemmEpi e = e_in;
     e.flops_hint = 2.0 * (double)(e.rows_valid > 0 ? e.rows_valid : rows_alloc) * (double)(L.n_true ? L.n_true : L.N_pad) *
                    (double)(L.k_true ? L.k_true : L.K_pad);
+    p.stagger = g_gemm_stagger;
     p.W = L.W; p.K_pad = L.K_pad; p.bias = L.bias; p.colvec = L.colvec; p.N_pad = L.N_pad;
     p.e = e;
     if (epi_kind == EPI_LINEAR) {
         if (!e.C || e.ldc < L.N_pad) throw Error(FC_ERR_INVALID, "launch_gemm: output pitch smaller than N_pad");
         if (L.N_pad <= 64) { p.nbm = rows_alloc / 128; launch_cfg<128, 64, 4, 1, EPI_LINEAR>(p, s); }
-        else if (L.N_pad % 128 == 0 || L.N_pad > 320) { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 2, 2, EPI_LINEAR>(p, s); }
+        else if (L.N_pad % 128 == 0 || L.N_pad > 320) {
+            p.nbm = rows_alloc / 128;
+            if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
+            else if (g_gemm_variant == 1) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 1>(p, s);
+            else launch_cfg<128, 128, 2, 2, EPI_LINEAR, 2>(p, s);
+        }
         else { p.nbm = rows_alloc / 128; launch_cfg<128, 320, 4, 1, EPI_LINEAR>(p, s); }
     } else {
         if (!L.bias || L.N_pad % 64 != 0) throw Error(FC_ERR_INVALID, "launch_gemm: pair-packed epilogue needs bias and N_pad % 64 == 0");

@@ -253,7 +253,8 @@ PackedLinear pack_linear(DeviceArena& arena, const MatD& W, const VecD& bias, co
     if (L.nseg < 1 || L.nseg > 3) throw Error(FC_ERR_INVALID, "pack_linear: 1..3 segments");
     for (int i = 0; i < L.nseg; ++i) { L.seg_k[i] = seg_k[i]; ks += seg_k[i]; }
     if (ks != L.K_pad) throw Error(FC_ERR_INVALID, "pack_linear: segments do not cover K");
-    std::vector<float> w((size_t)L.N_pad * L.K_pad, 0.f), b(L.N_pad, 0.f), cv(L.N_pad, 0.f);
+    L.n_alloc = gemm_n_alloc(L.N_pad);
+    std::vector<float> w((size_t)L.n_alloc * L.K_pad, 0.f), b(L.n_alloc, 0.f), cv(L.n_alloc, 0.f);
     for (int n = 0; n < L.N_pad; ++n) {
         const int sn = nmap[n];
         if (sn < 0) continue;

@@ -23,7 +23,17 @@ struct TmpBuf {
     catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; } \
     return FC_OK;
 
+namespace fc { extern int g_gemm_variant, g_gemm_stagger; }
+
 extern "C" {
+
+/* tuning knobs for profiles/kernel_bench.py (not part of the stable ABI surface in fcflow.h on purpose) */
+int fc_debug_set(int32_t key, int32_t value) {
+    if (key == 0) fc::g_gemm_variant = value;
+    else if (key == 1) fc::g_gemm_stagger = value;
+    else return FC_ERR_INVALID;
+    return FC_OK;
+}
 
 int fc_op_linear_f32(const float* x, const float* W, const float* bias, const float* residual, float* y, int32_t rows, int32_t N, int32_t K,
                      int32_t act, void* stream) {
@@ -32,10 +42,11 @@ int fc_op_linear_f32(const float* x, const float* W, const float* bias, const fl
     if (!x || !W || !y || rows < 1 || N < 1 || K < 1) throw Error(FC_ERR_INVALID, "fc_op_linear_f32: bad argument");
     hipStream_t s = (hipStream_t)stream;
     const int rp = round_up(rows, ROW_PAD), np = round_up(N, 32), kp = round_up(K, 32);
-    TmpBuf xp((size_t)rp * kp * 4), wp((size_t)np * kp * 4), bp((size_t)np * 4), cp((size_t)rp * np * 4), rpad(residual ? (size_t)rp * np * 4 : 4);
+    const int na = gemm_n_alloc(np);
+    TmpBuf xp((size_t)rp * kp * 4), wp((size_t)na * kp * 4), bp((size_t)na * 4), cp((size_t)rp * np * 4), rpad(residual ? (size_t)rp * np * 4 : 4);
     launch_fill(xp.f(), 0.f, (size_t)rp * kp, s);
-    launch_fill(wp.f(), 0.f, (size_t)np * kp, s);
-    launch_fill(bp.f(), 0.f, (size_t)np, s);
+    launch_fill(wp.f(), 0.f, (size_t)na * kp, s);
+    launch_fill(bp.f(), 0.f, (size_t)na, s);
     launch_pack_rows(x, K, K, xp.f(), kp, 0, K, rows, s);
     launch_pack_rows(W, K, K, wp.f(), kp, 0, K, N, s);
     if (bias) launch_pack_rows(bias, N, N, bp.f(), np, 0, N, 1, s);
@@ -44,7 +55,8 @@ int fc_op_linear_f32(const float* x, const float* W, const float* bias, const fl
         launch_pack_rows(residual, N, N, rpad.f(), np, 0, N, rows, s);
     }
     PackedLinear L;
-    L.W = wp.f(); L.bias = bp.f(); L.N_pad = np; L.K_pad = kp; L.nseg = 1; L.seg_k[0] = kp;
+    L.W = wp.f(); L.bias = bp.f(); L.N_pad = np; L.K_pad = kp; L.nseg = 1; L.seg_k[0] = kp; L.n_alloc = na;
+    L.n_true = N; L.k_true = K;
     GemmEpi e{};
     e.act = act; e.C = cp.f(); e.ldc = np;
     if (residual) { e.residual = rpad.f(); e.ldr = np; }
