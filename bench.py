@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import flowcompare_amd as fa  # noqa: E402
-from flowcompare_amd import engine  # noqa: E402
+from flowcompare_amd import engine, shard  # noqa: E402
 
 # SURVEY.md §8(d) / BASELINE.md §4: algorithmic MFLOP per target point (1 MAC = 2 FLOP), by config
 ALG_MFLOP_PER_POINT = {"c1_dgcnn_global_affine": 396.0, "c2_dgcnn_attn_spline": 859.0, "c4_dgcnn_attn_extra_affine": 453.0}
@@ -126,10 +126,7 @@ def main():
     def step():
         loss, lp, bpd = fa.inner_loop(batch, md, cfg, eps=eps)
         if dist is not None:                              # global mean over all ranks' scenes: the only exchange of the path
-            t = torch.stack((lp.sum(), torch.tensor(float(lp.numel()), device=dev)))
-            dist.all_reduce(t)
-            loss = -(t[0] / t[1])
-            bpd = loss * math.log2(math.e) / cfg["input_dim"]
+            loss, bpd = shard.global_loss_bpd(lp, cfg["input_dim"])
         return loss, lp, bpd
 
     t_build = time.perf_counter()

@@ -31,6 +31,7 @@ struct GemmParams {
     const float* colvec;
     int N_pad;
     int nbm, nbn;
+    int col_group;      // > 0: row-band / column-group tile order for weight matrices that do not fit L2
     int stagger;
     GemmEpi e;
 };
@@ -97,15 +98,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     const int wr = wave / WN, wc = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    // XCD-aware tile order: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous run of
-    // (row-tile, col-tile) pairs with the col-tile fastest so the A row panel is fetched from HBM once.
+    // XCD-aware tile order.  Blocks b, b+8, ... share an XCD (and its 4 MiB L2).
+    //  * small weight matrix (fits L2 beside the activations): each XCD takes a contiguous run of (row-tile, col-tile)
+    //    pairs with the col-tile fastest, so an A row panel is fetched from HBM once and W stays L2 resident;
+    //  * large weight matrix (p.col_group > 0, e.g. the 3750-wide spline parameter layer, W = 7.7 MB): each XCD owns a
+    //    band of row tiles and walks it in groups of col_group column tiles, so that group of W tiles stays in L2 while
+    //    the band's A panels stream past (measured before: 5x the algorithmic bytes were re-fetched through L2).
     int bm, bn;
     {
         const int nb = p.nbm * p.nbn, b = blockIdx.x;
-        const int xcd = b & 7, q = nb >> 3, r = nb & 7;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-        bm = L / p.nbn;
-        bn = L - bm * p.nbn;
+        const int xcd = b & 7, loc = b >> 3;
+        if (p.col_group > 0) {
+            const int rows_x = p.nbm >> 3, G = p.col_group;           // launcher guarantees nbm % 8 == 0
+            const int g = loc / (rows_x * G);
+            const int rem = loc - g * rows_x * G;
+            const int w = p.nbn - g * G < G ? p.nbn - g * G : G;
+            const int r = rem / w;
+            bm = xcd * rows_x + r;
+            bn = g * G + (rem - r * w);
+        } else {
+            const int q = nb >> 3, r = nb & 7;
+            const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+            bm = L / p.nbn;
+            bn = L - bm * p.nbn;
+        }
     }
     const int m0 = bm * BM, n0 = bn * BN;
     const int wave_n0 = n0 + wc * TN * 32;
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 2, g_gemm_stagger = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 2, g_gemm_stagger = 0, g_gemm_colgroup = 10;     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
@@ -331,6 +347,9 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
     }
     GemmParams q = p;
     q.nbn = (p.N_pad + BN - 1) / BN;
+    q.col_group = 0;
+    if ((size_t)p.N_pad * p.K_pad * sizeof(float) > (size_t)(3u << 19) && q.nbm % 8 == 0 && q.nbn > g_gemm_colgroup && g_gemm_colgroup > 0)
+        q.col_group = g_gemm_colgroup;
     char name[96];
     snprintf(name, sizeof name, "void fc::gemm_f32_kernel<%d, %d, %d, %d, %d, %d>(fc::GemmParams)", BM, BN, WM, WN, EPI, VAR);
     ProfScope ps(name, p.e.flops_hint, 0.0, s);

@@ -23,7 +23,7 @@ struct TmpBuf {
     catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; } \
     return FC_OK;
 
-namespace fc { extern int g_gemm_variant, g_gemm_stagger; }
+namespace fc { extern int g_gemm_variant, g_gemm_stagger, g_gemm_colgroup; }
 
 extern "C" {
 
@@ -31,6 +31,7 @@ extern "C" {
 int fc_debug_set(int32_t key, int32_t value) {
     if (key == 0) fc::g_gemm_variant = value;
     else if (key == 1) fc::g_gemm_stagger = value;
+    else if (key == 2) fc::g_gemm_colgroup = value;
     else return FC_ERR_INVALID;
     return FC_OK;
 }

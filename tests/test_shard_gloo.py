@@ -1,0 +1,72 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercising the scene sharding + the scalar loss reduction + the log-prob
+gather.  The per-rank compute is the pinned oracle here (this container has no GPU); on the GPU box the same helpers wrap
+the HIP engine (bench.py)."""
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import Fixture
+from flowcompare_amd import shard
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from oracle import flow_oracle as O
+        fx = Fixture("e2e_tiny_affine")                       # B = 3 scenes: uneven split 2 + 1
+        cfg = fx.derived_cfg()
+        sd_flow, sd_emb = fx.state_dicts(torch.float64)
+        batch = (fx.t("extract_0", torch.float64), fx.t("extract_1", torch.float64), fx.t("extra", torch.float64))
+        eps = fx.eps(torch.float64)
+        lo, hi = shard.shard_bounds(3, rank, world)
+        local = shard.shard_batch(batch, rank, world)
+        assert local[0].shape[0] == hi - lo
+        with torch.no_grad():
+            _, lp, _ = O.inner_loop(cfg, sd_flow, sd_emb, local, [e[lo:hi] for e in eps])
+        loss, bpd = shard.global_loss_bpd(lp, cfg["input_dim"])
+        full = shard.gather_log_prob(lp, 3)
+        q.put((rank, float(loss), float(bpd), full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharding_reproduces_single_process_result():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    fx = Fixture("e2e_tiny_affine")
+    for rank, loss, bpd, full in res:
+        assert abs(loss - float(fx.a["loss_f64"])) < 1e-9 and abs(bpd - float(fx.a["bpd_f64"])) < 1e-10
+        assert abs(full - fx.a["log_prob_f64"]).max() < 1e-8
+
+
+def test_shard_bounds_cover_batch_exactly():
+    for B in (1, 2, 3, 16, 17, 64, 128):
+        for G in (1, 2, 3, 4, 8):
+            spans = [shard.shard_bounds(B, r, G) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
