@@ -98,7 +98,7 @@ inline int gemm_n_alloc(int N_pad) {
 // A operand segment: rows x seg_k floats starting at ptr with row pitch lda
 struct ASeg { const float* ptr; int lda; };
 
-enum Epilogue { EPI_LINEAR = 0, EPI_AFFINE = 1, EPI_AUGMENT = 2 };
+enum Epilogue { EPI_LINEAR = 0, EPI_AFFINE = 1, EPI_AUGMENT = 2, EPI_SLICE = 3 };
 
 struct GemmEpi {
     // EPI_LINEAR
@@ -114,7 +114,12 @@ struct GemmEpi {
     int scale_fn = FC_SCALE_SIGMOID;
     float* logprob = nullptr;  // [rows_valid]
     const float* eps = nullptr; int d_in = 0, d1 = 0, d1_pad = 0;   // AUGMENT: latent index = d_in + q ; x1|x2 split
-    float clamp = 0.f;         // AUGMENT/CIF: std clamp (0 = none)
+    float clamp = 0.f;         // AUGMENT/SLICE: std clamp (0 = none)
+    int inverse = 0;           // AFFINE: x2 = (y2 - t) / (s*g), no log-det ; AUGMENT: sample only (no log-det)
+    int split = 1 << 30, split_pad = 0;   // AFFINE: transformed dim j lives at column x2_col0 + (j < split ? j : split_pad + j - split)
+    const float* post_scale = nullptr;    // AFFINE: optional per-dim factor g folded behind s (CIF: ActNorm of the x part)
+    const float* val = nullptr; int ldval = 0;             // SLICE: values whose log N(.; mu, sigma) is ADDED to logprob
+    const float* val_shift = nullptr; const float* val_scale = nullptr;   // SLICE: v = (val - shift) * scale ; AUGMENT(+inverse): z = z / scale + shift
     int rows_valid = 0;        // rows that exist in user-visible outputs
     double flops_hint = 0.0;   // filled by launch_gemm for the profiler
 };
@@ -135,6 +140,8 @@ void launch_base_density(const float* x, int ldx, int d1, int d1_pad, int d2, fl
                          float* z_out, int D, int rows, hipStream_t s);
 void launch_spline(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows,
                    int inverse, hipStream_t s);
+void launch_expm_coupling(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, const float* scal4, float* logprob,
+                          int rows, int inverse, hipStream_t s);
 void launch_spline_flat(const float* x, const float* params, float* y, float* lad, int64_t n, int K, int inverse, hipStream_t s);
 void launch_knn(const float* f, int ldf, int C, int32_t* idx, int B, int M, int m_stride_rows, int k, hipStream_t s);
 void launch_gather_max(const float* uv, int lduv, int c_out, const int32_t* idx, int k, float* out, int ldo, int out_col0,

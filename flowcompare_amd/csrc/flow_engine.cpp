@@ -26,13 +26,30 @@ struct AttnPack {
     int kv_col = 0;      // column of this layer's [K | V] block inside the kv buffer
 };
 
+// CIFblock pieces (models/cif_block.py:49-112), all expressed in the NATURAL index order of x (D) and z2 (Dc - D): the two
+// Reverse permutations are folded into the packed weights' row / column maps.
+struct CifPack {
+    PackedMLP dist;               // shared ConditionalNormal net of augmenter and slicer: x (x layout) -> [mean | log_std] pairs
+    PackedMLP aff;                // affine_cif: flip(z2) -> (s, t) for flip(x); t rows carry the x-part ActNorm
+    float* post_scale = nullptr;  // g[k] = exp(-log_scale) of the x part (behind s)
+    float* z2_shift = nullptr;    // ActNorm of the z2 part: v = (z2 - shift) * scale
+    float* z2_scale = nullptr;
+};
+
 struct BlockPack {
     bool has_attn = false;
     PackedMLP pre;       // pre_attention_mlp
     AttnPack attn;
     PackedMLP net;       // coupling MLP (in_layer has the folded context segment)
+    float* expm_scal = nullptr;   // ExponentialCoupling: {scale, shift, rescale, reshift}
+    bool has_cif = false;
+    CifPack cif;
     bool has_lin = false;
     PackedLinear lin;    // folded ActNorm + permuter (absent after the last block)
+    MatD lin_w;          // host copy (double) for the lazily built inverse
+    VecD lin_b;
+    bool has_lin_inv = false;
+    PackedLinear lin_inv;
 };
 
 struct Dims {
@@ -40,7 +57,8 @@ struct Dims {
     int E, E_pad, X;
     int A_in = 0, A_in_pad = 0, I = 0, I_pad = 0;
     int H_pad = 0;       // widest hidden activation
-    int ldp = 0;         // spline parameter pitch
+    int ldp = 0;         // spline / expm parameter pitch
+    int Dc = 0, nz = 0, nz_pad = 0;   // CIF: cif_latent_dim, Dc - D
 };
 
 }  // namespace fc
@@ -214,10 +232,12 @@ static void build_lin(fc_flow& f, const WeightTable& wt, int idx_actnorm, int id
     const std::vector<int> xl = map_xlayout(d.d1, d.d1_pad, d.d2, d.d2_pad);
     blk.lin = pack_linear(f.arena, Wp, b, {}, xl, xl, {d.ldx});
     blk.has_lin = true;
+    blk.lin_w = Wp;
+    blk.lin_b = b;
 }
 
 static void build_out_layer(fc_flow& f, const WeightTable& wt, const std::string& prefix, PackedMLP& net) {
-    const Dims& d = f.d;
+    Dims& d = f.d;
     const int hl = net.sizes.back();
     const HostTensor& w = wt.get(prefix + ".out_layer.weight");
     const int n = (int)w.shape[0];
@@ -232,9 +252,79 @@ static void build_out_layer(fc_flow& f, const WeightTable& wt, const std::string
         if (n != per * d.d2) throw Error(FC_ERR_UNSUPPORTED, "spline coupling with odd latent_dim fails in the reference too (reshape)");
         nmap = map_prefix(n, round_up(n, 32));
     } else {
-        throw Error(FC_ERR_UNSUPPORTED, "ExponentialCoupling is not built yet");
+        if (n != d.d2 * d.d2 + d.d2) throw Error(FC_ERR_SHAPE, prefix + ".out_layer: exponential coupling expects d2^2 + d2 outputs");
+        nmap = map_prefix(n, round_up(n, 32));
     }
     net.out_layer = pack_linear(f.arena, mat_from(w), b, {}, nmap, map_prefix(hl, round_up(hl, 32)), {round_up(hl, 32)});
+}
+
+// pair-packed row map from explicit (first-half row, second-half row) lists
+static std::vector<int> map_pairs_rows(const std::vector<int>& first, const std::vector<int>& second) {
+    const int n = (int)first.size(), np = (n + 31) / 32;
+    std::vector<int> m(np * 64, -1);
+    for (int j = 0; j < n; ++j) { m[64 * (j / 32) + j % 32] = first[j]; m[64 * (j / 32) + 32 + j % 32] = second[j]; }
+    return m;
+}
+
+// CIFblock (models/cif_block.py:49-112).  Natural-order algebra (x: D dims, z2: nz = Dc - D dims, Reverse folded away):
+//   z2 = mu(x) + eps sigma(x)                                   ldj -= log N(z2)
+//   (s,t) = affine_cif.nn(flip(z2)),  zx[k] = (x[k] s'[k] + t'[k] - shift[Dc-1-k]) e^{-log_scale[Dc-1-k]},  s'[k] = s[D-1-k]   ldj += sum log s
+//   x2n[j] = (z2[j] - shift[nz-1-j]) e^{-log_scale[nz-1-j]}      ldj += sum(-log_scale)  (constant)
+//   ldj += log N(x2n; mu(zx), sigma(zx))                         (Slice with the SAME distribution object)
+//   then the attention-conditioned coupling on zx.
+static void build_cif(fc_flow& f, const WeightTable& wt, const std::string& p, CifPack& c) {
+    Dims& d = f.d;
+    const int D = d.D, nz = d.nz, Dc = d.Dc;
+    const std::string pd = p + ".augmenter.noise_dist.net";
+    if (wt.has(p + ".slicer.noise_dist.net.in_layer.weight")) {          // shared object: both prefixes must hold the same values
+        const HostTensor& a = wt.get(pd + ".in_layer.weight");
+        const HostTensor& b = wt.get(p + ".slicer.noise_dist.net.in_layer.weight");
+        if (a.shape != b.shape || memcmp(a.data, b.data, sizeof(float) * (size_t)a.numel()) != 0)
+            throw Error(FC_ERR_INVALID, p + ": augmenter.noise_dist and slicer.noise_dist must be identical (one shared ConditionalNormal)");
+    }
+    pack_mlp_mid(f.arena, wt, pd, c.dist);
+    {
+        const HostTensor& w = wt.get(pd + ".in_layer.weight");
+        if (w.shape.size() != 2 || w.shape[1] != D) throw Error(FC_ERR_SHAPE, pd + ".in_layer.weight: expected input width latent_dim");
+        const int h = (int)w.shape[0];
+        c.dist.in_layer = pack_linear(f.arena, mat_from(w), vec_from(wt.get(pd + ".in_layer.bias", {h})), {}, map_prefix(h, round_up(h, 32)),
+                                      map_xlayout(d.d1, d.d1_pad, d.d2, d.d2_pad), {d.ldx});
+        const int hl = c.dist.sizes.back();
+        const HostTensor& wo = wt.get(pd + ".out_layer.weight", {2 * nz, hl});
+        c.dist.out_layer = pack_linear(f.arena, mat_from(wo), vec_from(wt.get(pd + ".out_layer.bias", {2 * nz})), {}, map_pairs(nz, nz),
+                                       map_prefix(hl, round_up(hl, 32)), {round_up(hl, 32)});
+    }
+    VecD shift = vec_from(wt.get(p + ".act_norm.shift", {1, Dc})), ls = vec_from(wt.get(p + ".act_norm.log_scale", {1, Dc}));
+    for (double v : ls) f.log_const -= v;
+    std::vector<float> g(gemm_n_alloc(round_up(D, 32) * 2), 0.f), sh2(gemm_n_alloc(round_up(nz, 32) * 2), 0.f), g2(sh2.size(), 1.f);
+    for (int k = 0; k < D; ++k) g[k] = (float)std::exp(-ls[Dc - 1 - k]);
+    for (int j = 0; j < nz; ++j) { sh2[j] = (float)shift[nz - 1 - j]; g2[j] = (float)std::exp(-ls[nz - 1 - j]); }
+    c.post_scale = f.arena.upload(g);
+    c.z2_shift = f.arena.upload(sh2);
+    c.z2_scale = f.arena.upload(g2);
+    const std::string pa = p + ".affine_cif.nn";
+    pack_mlp_mid(f.arena, wt, pa, c.aff);
+    {
+        const HostTensor& w = wt.get(pa + ".in_layer.weight");
+        if (w.shape.size() != 2 || w.shape[1] != nz) throw Error(FC_ERR_SHAPE, pa + ".in_layer.weight: expected input width cif_latent_dim - latent_dim");
+        const int h = (int)w.shape[0];
+        std::vector<int> km(d.nz_pad, -1);
+        for (int j = 0; j < nz; ++j) km[j] = nz - 1 - j;                   // input arrives as z2 in natural order; the net saw flip(z2)
+        c.aff.in_layer = pack_linear(f.arena, mat_from(w), vec_from(wt.get(pa + ".in_layer.bias", {h})), {}, map_prefix(h, round_up(h, 32)), km, {d.nz_pad});
+        const int hl = c.aff.sizes.back();
+        MatD wo = mat_from(wt.get(pa + ".out_layer.weight", {2 * D, hl}));
+        VecD bo = vec_from(wt.get(pa + ".out_layer.bias", {2 * D}));
+        std::vector<int> srow(D), trow(D);
+        for (int k = 0; k < D; ++k) {
+            const int i = D - 1 - k;                                       // position inside flip(x)
+            srow[k] = i; trow[k] = D + i;
+            const double gk = std::exp(-ls[Dc - 1 - k]);
+            for (int c2 = 0; c2 < hl; ++c2) wo.at(D + i, c2) *= gk;          // t'' = (t - shift) g
+            bo[D + i] = (bo[D + i] - shift[Dc - 1 - k]) * gk;
+        }
+        c.aff.out_layer = pack_linear(f.arena, wo, bo, {}, map_pairs_rows(srow, trow), map_prefix(hl, round_up(hl, 32)), {round_up(hl, 32)});
+    }
+    d.H_pad = std::max({d.H_pad, max_hidden_pad(c.dist), max_hidden_pad(c.aff)});
 }
 
 static void build_flow(fc_flow& f, const WeightTable& wt) {
@@ -243,13 +333,17 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
     if (c.struct_size != (int)sizeof(fc_flow_config)) throw Error(FC_ERR_INVALID, "fc_flow_config.struct_size mismatch (ABI)");
     if (c.latent_dim < c.input_dim) throw Error(FC_ERR_INVALID, "Latent dim < Input dim");
     if (c.cif_latent_dim < c.latent_dim) throw Error(FC_ERR_INVALID, "Augment dim smaller than main latent!");
-    if (c.cif_latent_dim > c.latent_dim) throw Error(FC_ERR_UNSUPPORTED, "CIFblock (cif_latent_dim > latent_dim) is not built yet");
+    const bool cif = c.cif_latent_dim > c.latent_dim;
+    if (cif && c.extra_context_dim) throw Error(FC_ERR_INVALID, "Not implemented extra context with cif");
+    if (cif && c.global_context) throw Error(FC_ERR_INVALID, "CIF + global embedding not implemented");
     if (c.n_flow_layers < 1 || c.latent_dim < 2) throw Error(FC_ERR_INVALID, "need n_flow_layers >= 1 and latent_dim >= 2");
     if (c.extra_context_dim < 0 || c.extra_context_dim > 1) throw Error(FC_ERR_UNSUPPORTED, "extra_context_dim must be 0 or 1");
     d.Din = c.input_dim; d.D = c.latent_dim; d.d1 = d.D / 2; d.d2 = d.D - d.d1;
     d.d1_pad = round_up(d.d1, 32); d.d2_pad = round_up(d.d2, 32); d.ldx = d.d1_pad + d.d2_pad;
     d.E = c.input_embedding_dim; d.E_pad = round_up(d.E, 32); d.X = c.extra_context_dim;
     if (d.Din > 32) throw Error(FC_ERR_UNSUPPORTED, "input_dim > 32");
+    d.Dc = c.cif_latent_dim; d.nz = d.Dc - d.D; d.nz_pad = round_up(std::max(d.nz, 1), 32);
+    if (cif && d.D > 160) throw Error(FC_ERR_UNSUPPORTED, "CIFblock with latent_dim > 160 is not supported yet (single-tile affine_cif epilogue)");
     std::vector<MatD> kv_rows;
 
     // ---- transform 0: AugmentAttentionPreconditioner (models/augmenter.py:7-22) or IdentityTransform
@@ -275,8 +369,13 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
     f.blocks.resize(c.n_flow_layers);
     for (int l = 0; l < c.n_flow_layers; ++l) {
         BlockPack& b = f.blocks[l];
-        const std::string p = "transforms." + std::to_string(idx++);
+        std::string p = "transforms." + std::to_string(idx++);
         b.has_attn = !c.global_context;
+        b.has_cif = cif;
+        if (cif) {
+            build_cif(f, wt, p, b.cif);
+            p += ".flow";                              // the conditioned coupling lives one level down (cif_block.py:65)
+        }
         if (b.has_attn) {
             build_attn(f, wt, p + ".pre_conditioner.attn", b.attn, kv_rows);
             const std::string pp = p + ".pre_conditioner.pre_attention_mlp";
@@ -291,7 +390,13 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
         b.net.in_layer = build_in_layer(f, wt, pn, d.d1, d.d1_pad, b.has_attn ? &b.attn : nullptr);
         build_out_layer(f, wt, pn, b.net);
         d.H_pad = std::max(d.H_pad, max_hidden_pad(b.net));
-        if (c.flow_type == FC_FLOW_SPLINE) d.ldp = std::max(d.ldp, b.net.out_layer.N_pad);
+        if (c.flow_type != FC_FLOW_AFFINE) d.ldp = std::max(d.ldp, b.net.out_layer.N_pad);
+        if (c.flow_type == FC_FLOW_EXPONENTIAL) {
+            const std::string pt = p + ".transform";
+            std::vector<float> sc = {wt.get(pt + ".scale", {1}).data[0], wt.get(pt + ".shift", {1}).data[0],
+                                     wt.get(pt + ".rescale", {1}).data[0], wt.get(pt + ".reshift", {1}).data[0]};
+            b.expm_scal = f.arena.upload(sc);
+        }
         if (l != c.n_flow_layers - 1) {
             const int ia = c.act_norm ? idx++ : -1;
             const int ip = idx++;
@@ -309,7 +414,7 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
 
 // ---------------------------------------------------------------- workspace plan
 struct FlowWs {
-    float *xa, *xb, *h[3], *q, *a, *ctxp, *kv, *xin, *rowscal, *spl;
+    float *xa, *xb, *h[3], *q, *a, *ctxp, *kv, *xin, *rowscal, *spl, *cbuf;
     int P, P_pad, Pc, Pc_pad, ldkv;
 };
 static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t bytes, bool dry, size_t* need) {
@@ -329,19 +434,21 @@ static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t by
     w.xin = c.floats((size_t)w.P_pad * 32);
     w.rowscal = c.floats((size_t)w.P_pad);
     w.spl = c.floats(d.ldp ? (size_t)w.P_pad * d.ldp : 1);
+    w.cbuf = c.floats(d.nz > 0 ? (size_t)w.P_pad * d.nz_pad : 1);
     if (need) *need = c.off + 256;
     return w;
 }
 
-static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_segs, const float* rowscal, FlowWs& w, int rows, hipStream_t s) {
-    return run_mlp_hidden_generic(m, in_segs, rowscal, f.cfg.nonlinearity, w.h, std::max(f.d.H_pad, 32), rows, s, w.P);
+static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_segs, const float* rowscal, FlowWs& w, int act, hipStream_t s) {
+    return run_mlp_hidden_generic(m, in_segs, rowscal, act, w.h, std::max(f.d.H_pad, 32), w.P_pad, s, w.P);
 }
 
 // pre-conditioner: pre-MLP -> LayerNorm -> q -> attention; result in w.a  (models/cif_block.py:14-20 / augmenter.py:15-16)
-static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack& at, const ASeg& in, FlowWs& w, int B, int N, int M, hipStream_t s) {
+static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack& at, const ASeg& in, FlowWs& w, int act, int B, int N, int M,
+                          hipStream_t s) {
     const Dims& d = f.d;
     const int ldh = std::max(d.H_pad, 32);
-    const int cur = run_mlp_hidden(f, pre, &in, nullptr, w, w.P_pad, s);
+    const int cur = run_mlp_hidden(f, pre, &in, nullptr, w, act, s);
     int o = 0;
     while (o == cur) ++o;
     GemmEpi e{};
@@ -356,28 +463,99 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
     launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad, s);
 }
 
-static void flow_forward(fc_flow& f, const float* x, const float* ctx, const float* extra, const float* const* eps, int n_eps,
-                         float* logprob, float* z_out, int B, int N, int M, void* ws, size_t ws_bytes, hipStream_t s) {
+// the conditioned coupling of one block (PreConditionApplier, models/transform.py:47-58), forward or inverse, in place on xc
+static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, const float* rowscal, float* logprob, bool inverse, int B, int N,
+                         int M, hipStream_t s) {
+    const Dims& d = f.d;
+    const fc_flow_config& c = f.cfg;
+    const int ldh = std::max(d.H_pad, 32);
+    ASeg segs[2];
+    segs[0] = {xc, d.ldx};
+    if (b.has_attn) {
+        // CIFblock builds its pre_attention_mlp with GELU regardless of the configured nonlinearity (cif_block.py:61)
+        run_attention(f, b.pre, b.attn, segs[0], w, b.has_cif ? (int)FC_ACT_GELU : c.nonlinearity, B, N, M, s);
+        segs[1] = {w.a, d.I_pad};
+    } else {
+        segs[1] = {w.ctxp, d.E_pad};
+    }
+    const int cur = run_mlp_hidden(f, b.net, segs, rowscal, w, c.nonlinearity, s);
+    ASeg a{w.h[cur], ldh};
+    if (c.flow_type == FC_FLOW_AFFINE) {
+        GemmEpi e{};
+        e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = d.d1_pad; e.d2 = d.d2; e.scale_fn = c.affine_scale_fn;
+        e.logprob = logprob; e.rows_valid = w.P; e.inverse = inverse;
+        launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_AFFINE, s);
+    } else {
+        GemmEpi e{};
+        e.C = w.spl; e.ldc = d.ldp; e.rows_valid = w.P;
+        launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_LINEAR, s);
+        if (c.flow_type == FC_FLOW_SPLINE)
+            launch_spline(w.spl, d.ldp, xc, d.ldx, d.d1_pad, d.d2, c.num_bins_spline, logprob, w.P, inverse, s);
+        else
+            launch_expm_coupling(w.spl, d.ldp, xc, d.ldx, d.d1_pad, d.d2, b.expm_scal, logprob, w.P, inverse, s);
+    }
+}
+
+// CIF: net(x) -> [mean | log_std] pairs with the given pair epilogue
+static void run_cif_dist(fc_flow& f, const CifPack& cp, FlowWs& w, float* xc, GemmEpi e, int epi, hipStream_t s) {
+    ASeg in{xc, f.d.ldx};
+    const int cur = run_mlp_hidden(f, cp.dist, &in, nullptr, w, FC_ACT_GELU, s);
+    ASeg a{w.h[cur], std::max(f.d.H_pad, 32)};
+    e.clamp = f.cfg.clamp_dist; e.d2 = f.d.nz; e.rows_valid = w.P;
+    launch_gemm(cp.dist.out_layer, &a, w.P_pad, e, epi, s);
+}
+static void run_cif_affine(fc_flow& f, const CifPack& cp, FlowWs& w, float* xc, float* logprob, bool inverse, hipStream_t s) {
+    const Dims& d = f.d;
+    ASeg in{w.cbuf, d.nz_pad};
+    const int cur = run_mlp_hidden(f, cp.aff, &in, nullptr, w, FC_ACT_GELU, s);
+    ASeg a{w.h[cur], std::max(d.H_pad, 32)};
+    GemmEpi e{};
+    e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = 0; e.split = d.d1; e.split_pad = d.d1_pad; e.d2 = d.D; e.scale_fn = FC_SCALE_SIGMOID;
+    e.post_scale = cp.post_scale; e.logprob = logprob; e.rows_valid = w.P; e.inverse = inverse;
+    launch_gemm(cp.aff.out_layer, &a, w.P_pad, e, EPI_AFFINE, s);
+}
+
+struct Prep {
+    FlowWs w;
+    const float* rowscal = nullptr;
+};
+static Prep prepare(fc_flow& f, const float* ctx, const float* extra, int B, int N, int M, void* ws, size_t ws_bytes, hipStream_t s) {
     const Dims& d = f.d;
     const fc_flow_config& c = f.cfg;
     if (B < 1 || N < 1 || M < 1) throw Error(FC_ERR_INVALID, "B, N, M must be positive");
-    if (!x || !ctx || !logprob) throw Error(FC_ERR_INVALID, "null x / ctx / logprob");
+    if (!ctx) throw Error(FC_ERR_INVALID, "null ctx");
     if (d.X && !extra) throw Error(FC_ERR_INVALID, "this flow was built with extra context: extra must not be NULL");
     if (c.global_context && M != N) throw Error(FC_ERR_INVALID, "global context is per target point: ctx must be [B,N,E] (M == N)");
-    if (n_eps != (f.has_augment ? 1 : 0) || (n_eps && (!eps || !eps[0]))) throw Error(FC_ERR_INVALID, "wrong number of noise tensors");
-    FlowWs w = plan_ws(f, B, N, M, ws, ws_bytes, false, nullptr);
-    const int ldh = std::max(d.H_pad, 32);
-    const float* rowscal = nullptr;
-
-    launch_fill(logprob, 0.f, (size_t)w.P, s);
+    Prep p;
+    p.w = plan_ws(f, B, N, M, ws, ws_bytes, false, nullptr);
+    FlowWs& w = p.w;
     launch_pack_rows(ctx, d.E, d.E, w.ctxp, d.E_pad, 0, d.E_pad, w.Pc, s);
-    if (d.X) { launch_repeat_extra(extra, d.X, w.rowscal, B, N, s); rowscal = w.rowscal; }
+    if (d.X) { launch_repeat_extra(extra, d.X, w.rowscal, B, N, s); p.rowscal = w.rowscal; }
     if (f.n_attn) {
         GemmEpi e{};
         e.C = w.kv; e.ldc = w.ldkv; e.rows_valid = w.Pc;
         ASeg a{w.ctxp, d.E_pad};
         launch_gemm(f.kv_all, &a, w.Pc_pad, e, EPI_LINEAR, s);
     }
+    if (d.nz > 0) launch_fill(w.cbuf, 0.f, (size_t)w.P_pad * d.nz_pad, s);
+    return p;
+}
+
+static int expected_noise(const fc_flow& f) { return (f.has_augment ? 1 : 0) + (f.d.nz > 0 ? f.cfg.n_flow_layers : 0); }
+
+static void flow_forward(fc_flow& f, const float* x, const float* ctx, const float* extra, const float* const* eps, int n_eps,
+                         float* logprob, float* z_out, int B, int N, int M, void* ws, size_t ws_bytes, hipStream_t s) {
+    const Dims& d = f.d;
+    const fc_flow_config& c = f.cfg;
+    if (!x || !logprob) throw Error(FC_ERR_INVALID, "null x / logprob");
+    if (n_eps != expected_noise(f)) throw Error(FC_ERR_INVALID, "wrong number of noise tensors");
+    for (int i = 0; i < n_eps; ++i) if (!eps || !eps[i]) throw Error(FC_ERR_INVALID, "null noise tensor");
+    Prep pr = prepare(f, ctx, extra, B, N, M, ws, ws_bytes, s);
+    FlowWs& w = pr.w;
+    const int ldh = std::max(d.H_pad, 32);
+    int eps_i = 0;
+
+    launch_fill(logprob, 0.f, (size_t)w.P, s);
     float* xc = w.xa;
     float* xn = w.xb;
     launch_fill(xc, 0.f, (size_t)w.P_pad * d.ldx, s);
@@ -387,11 +565,11 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
         launch_pack_rows(x, d.Din, n1, xc, d.ldx, 0, n1, w.P, s);
         if (d.Din > n1) launch_pack_rows(x + n1, d.Din, d.Din - n1, xc, d.ldx, d.d1_pad, d.Din - n1, w.P, s);
         ASeg in{w.xin, 32};
-        run_attention(f, f.aug_pre, f.aug_attn, in, w, B, N, M, s);
+        run_attention(f, f.aug_pre, f.aug_attn, in, w, c.nonlinearity, B, N, M, s);
         ASeg segs[2] = {{w.xin, 32}, {w.a, d.I_pad}};
-        const int cur = run_mlp_hidden(f, f.aug_net, segs, rowscal, w, w.P_pad, s);
+        const int cur = run_mlp_hidden(f, f.aug_net, segs, pr.rowscal, w, c.nonlinearity, s);
         GemmEpi e{};
-        e.xbuf = xc; e.ldx = d.ldx; e.d2 = d.D - d.Din; e.logprob = logprob; e.eps = eps[0];
+        e.xbuf = xc; e.ldx = d.ldx; e.d2 = d.D - d.Din; e.logprob = logprob; e.eps = eps[eps_i++];
         e.d_in = d.Din; e.d1 = d.d1; e.d1_pad = d.d1_pad; e.rows_valid = w.P;
         ASeg a{w.h[cur], ldh};
         launch_gemm(f.aug_net.out_layer, &a, w.P_pad, e, EPI_AUGMENT, s);
@@ -400,28 +578,17 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
         launch_pack_rows(x + d.d1, d.D, d.d2, xc, d.ldx, d.d1_pad, d.d2, w.P, s);
     }
     for (int l = 0; l < c.n_flow_layers; ++l) {
-        const BlockPack& b = f.blocks[l];
-        ASeg segs[2];
-        segs[0] = {xc, d.ldx};
-        if (b.has_attn) {
-            run_attention(f, b.pre, b.attn, segs[0], w, B, N, M, s);
-            segs[1] = {w.a, d.I_pad};
-        } else {
-            segs[1] = {w.ctxp, d.E_pad};
+        BlockPack& b = f.blocks[l];
+        if (b.has_cif) {
+            GemmEpi ea{};                                   // Augment: z2 -> cbuf (natural order), ldj -= log N(z2)
+            ea.xbuf = w.cbuf; ea.ldx = d.nz_pad; ea.d_in = 0; ea.d1 = d.nz; ea.d1_pad = d.nz_pad; ea.logprob = logprob; ea.eps = eps[eps_i++];
+            run_cif_dist(f, b.cif, w, xc, ea, EPI_AUGMENT, s);
+            run_cif_affine(f, b.cif, w, xc, logprob, false, s);
+            GemmEpi es{};                                   // Slice: ldj += log N(actnorm(z2); mu(zx), sigma(zx))
+            es.val = w.cbuf; es.ldval = d.nz_pad; es.val_shift = b.cif.z2_shift; es.val_scale = b.cif.z2_scale; es.logprob = logprob;
+            run_cif_dist(f, b.cif, w, xc, es, EPI_SLICE, s);
         }
-        const int cur = run_mlp_hidden(f, b.net, segs, rowscal, w, w.P_pad, s);
-        ASeg a{w.h[cur], ldh};
-        if (c.flow_type == FC_FLOW_AFFINE) {
-            GemmEpi e{};
-            e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = d.d1_pad; e.d2 = d.d2; e.scale_fn = c.affine_scale_fn;
-            e.logprob = logprob; e.rows_valid = w.P;
-            launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_AFFINE, s);
-        } else {
-            GemmEpi e{};
-            e.C = w.spl; e.ldc = d.ldp; e.rows_valid = w.P;
-            launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_LINEAR, s);
-            launch_spline(w.spl, d.ldp, xc, d.ldx, d.d1_pad, d.d2, c.num_bins_spline, logprob, w.P, 0, s);
-        }
+        run_coupling(f, b, w, xc, pr.rowscal, logprob, false, B, N, M, s);
         if (b.has_lin) {
             GemmEpi e{};
             e.C = xn; e.ldc = d.ldx; e.rows_valid = w.P;
@@ -431,6 +598,56 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
         }
     }
     launch_base_density(xc, d.ldx, d.d1, d.d1_pad, d.d2, logprob, (float)f.log_const, z_out, d.D, w.P, s);
+}
+
+// Flow.sample's inverse pass (models/transform.py:79-84): transforms in reverse order, each inverted.
+static void flow_inverse(fc_flow& f, const float* z, const float* ctx, const float* extra, const float* const* eps, int n_eps, float* x_out,
+                         int B, int N, int M, void* ws, size_t ws_bytes, hipStream_t s) {
+    const Dims& d = f.d;
+    const fc_flow_config& c = f.cfg;
+    if (!z || !x_out) throw Error(FC_ERR_INVALID, "null z / x_out");
+    const int need_eps = d.nz > 0 ? c.n_flow_layers : 0;     // Slice.inverse draws once per CIF block (models/slice.py:46-58)
+    if (n_eps != need_eps) throw Error(FC_ERR_INVALID, "wrong number of noise tensors for the inverse pass");
+    for (int i = 0; i < n_eps; ++i) if (!eps || !eps[i]) throw Error(FC_ERR_INVALID, "null noise tensor");
+    for (auto& b : f.blocks)                                 // lazily invert the folded ActNorm+permuter matrices (double precision)
+        if (b.has_lin && !b.has_lin_inv) {
+            MatD inv = inverse_double(b.lin_w);
+            VecD bi(d.D, 0.0);
+            for (int i = 0; i < d.D; ++i) { double t = 0; for (int k = 0; k < d.D; ++k) t += inv.at(i, k) * b.lin_b[k]; bi[i] = -t; }
+            const std::vector<int> xl = map_xlayout(d.d1, d.d1_pad, d.d2, d.d2_pad);
+            b.lin_inv = pack_linear(f.arena, inv, bi, {}, xl, xl, {d.ldx});
+            b.has_lin_inv = true;
+        }
+    Prep pr = prepare(f, ctx, extra, B, N, M, ws, ws_bytes, s);
+    FlowWs& w = pr.w;
+    float* xc = w.xa;
+    float* xn = w.xb;
+    launch_fill(xc, 0.f, (size_t)w.P_pad * d.ldx, s);
+    launch_pack_rows(z, d.D, d.d1, xc, d.ldx, 0, d.d1, w.P, s);
+    launch_pack_rows(z + d.d1, d.D, d.d2, xc, d.ldx, d.d1_pad, d.d2, w.P, s);
+    int eps_i = 0;
+    for (int l = c.n_flow_layers - 1; l >= 0; --l) {
+        BlockPack& b = f.blocks[l];
+        if (b.has_lin) {
+            GemmEpi e{};
+            e.C = xn; e.ldc = d.ldx; e.rows_valid = w.P;
+            ASeg ax{xc, d.ldx};
+            launch_gemm(b.lin_inv, &ax, w.P_pad, e, EPI_LINEAR, s);
+            std::swap(xc, xn);
+        }
+        run_coupling(f, b, w, xc, pr.rowscal, nullptr, true, B, N, M, s);
+        if (b.has_cif) {
+            GemmEpi ea{};                                   // Slice.inverse: x2n ~ N(mu(z), sigma(z)); stored as z2 = x2n / g2 + shift2
+            ea.xbuf = w.cbuf; ea.ldx = d.nz_pad; ea.d_in = 0; ea.d1 = d.nz; ea.d1_pad = d.nz_pad; ea.eps = eps[eps_i++]; ea.inverse = 1;
+            ea.val_shift = b.cif.z2_shift; ea.val_scale = b.cif.z2_scale;
+            run_cif_dist(f, b.cif, w, xc, ea, EPI_AUGMENT, s);
+            run_cif_affine(f, b.cif, w, xc, nullptr, true, s);
+        }
+    }
+    // Augment.inverse keeps the first input_dim latent dims (models/augmenter.py:65-67)
+    const int n1 = std::min(d.Din, d.d1);
+    launch_pack_rows(xc, d.ldx, n1, x_out, d.Din, 0, n1, w.P, s);
+    if (d.Din > n1) launch_pack_rows(xc + d.d1_pad, d.ldx, d.Din - n1, x_out, d.Din, n1, d.Din - n1, w.P, s);
 }
 
 }  // namespace fc
@@ -482,10 +699,11 @@ int fc_flow_workspace_bytes(const fc_flow* flow, int32_t B, int32_t N, int32_t M
     FC_API_END
 }
 
-int fc_flow_noise_count(const fc_flow* flow) { return flow ? (flow->has_augment ? 1 : 0) : 0; }
+int fc_flow_noise_count(const fc_flow* flow) { return flow ? fc::expected_noise(*flow) : 0; }
 int fc_flow_noise_width(const fc_flow* flow, int32_t i) {
-    if (!flow || i != 0 || !flow->has_augment) return 0;
-    return flow->d.D - flow->d.Din;
+    if (!flow || i < 0 || i >= fc::expected_noise(*flow)) return 0;
+    if (flow->has_augment && i == 0) return flow->d.D - flow->d.Din;
+    return flow->d.nz;
 }
 
 int fc_flow_logprob_f32(fc_flow* flow, const float* x, const float* ctx, const float* extra, const float* const* eps, int32_t n_eps,
@@ -496,10 +714,12 @@ int fc_flow_logprob_f32(fc_flow* flow, const float* x, const float* ctx, const f
     FC_API_END
 }
 
-int fc_flow_inverse_f32(fc_flow*, const float*, const float*, const float*, const float* const*, int32_t, float*, int32_t, int32_t, int32_t,
-                        void*, size_t, void*) {
-    fc::set_last_error("fc_flow_inverse_f32: the sampling path (SURVEY.md §8f N2) is not built yet");
-    return FC_ERR_UNSUPPORTED;
+int fc_flow_inverse_f32(fc_flow* flow, const float* z, const float* ctx, const float* extra, const float* const* eps, int32_t n_eps, float* x_out,
+                        int32_t B, int32_t N, int32_t M, void* workspace, size_t workspace_bytes, void* stream) {
+    FC_API_BEGIN
+    if (!flow || !workspace) throw fc::Error(FC_ERR_INVALID, "fc_flow_inverse_f32: null flow / workspace");
+    fc::flow_inverse(*flow, z, ctx, extra, eps, n_eps, x_out, B, N, M, workspace, workspace_bytes, (hipStream_t)stream);
+    FC_API_END
 }
 
 }  // extern "C"

@@ -294,31 +294,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
                             const int row = wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                             const float u = acc[i][2 * pr][r] + bs, t = acc[i][2 * pr + 1][r] + bt;
                             if constexpr (EPI == EPI_AFFINE) {
-                                // models/affine_coupling.py:23-46: s = exp(u) | (2 sigmoid(u) - 1)(1 - 1e-8) + 1
-                                float s;
-                                if (e.scale_fn == FC_SCALE_EXP) s = expf(u);
-                                else s = (2.0f * (1.0f / (1.0f + expf(-u))) - 1.0f) * (float)(1.0 - 1e-8) + 1.0f;
-                                float* xp = e.xbuf + (size_t)row * e.ldx + e.x2_col0 + j;
-                                *xp = *xp * s + t;
-                                lsum[i][r] += logf(s);
-                            } else {
+                                // models/affine_coupling.py:23-62: s = exp(u) | (2 sigmoid(u) - 1)(1 - 1e-8) + 1 ; y2 = x2 s + t ; x2 = (y2 - t)/s
+                                float sc;
+                                if (e.scale_fn == FC_SCALE_EXP) sc = expf(u);
+                                else sc = (2.0f * (1.0f / (1.0f + expf(-u))) - 1.0f) * (float)(1.0 - 1e-8) + 1.0f;
+                                const float g = e.post_scale ? e.post_scale[j] : 1.0f;
+                                float* xp = e.xbuf + (size_t)row * e.ldx + e.x2_col0 + (j < e.split ? j : e.split_pad + (j - e.split));
+                                if (e.inverse) *xp = (*xp - t) / (sc * g);
+                                else { *xp = *xp * (sc * g) + t; lsum[i][r] += logf(sc); }
+                            } else if constexpr (EPI == EPI_AUGMENT) {
                                 // models/augmenter.py:49-63 + distributions.py:128-153: z2 = mu + eps*sigma, ldj = -log N(z2; mu, sigma)
                                 float sigma = expf(t);
                                 if (e.clamp > 0.f) sigma = fminf(sigma, e.clamp);
                                 const float ev = row < e.rows_valid ? e.eps[(size_t)row * e.d2 + j] : 0.f;
-                                const float z = u + ev * sigma;
+                                float z = u + ev * sigma;
                                 const float dz = z - u;
                                 const float lp = -(dz * dz) / (2.0f * sigma * sigma) - logf(sigma) - 0.91893853320467274178f;
+                                if (e.val_scale) z = z / e.val_scale[j] + e.val_shift[j];     // CIF Slice.inverse: undo the ActNorm of the z2 part
                                 const int idx = e.d_in + j;
                                 const int col = idx < e.d1 ? idx : e.d1_pad + (idx - e.d1);
                                 e.xbuf[(size_t)row * e.ldx + col] = z;
-                                lsum[i][r] -= lp;
+                                if (!e.inverse) lsum[i][r] -= lp;
+                            } else {
+                                // models/slice.py:31-44 + distributions.py:140-142: ldj = +log N(x2; mu(z), sigma(z))
+                                float sigma = expf(t);
+                                if (e.clamp > 0.f) sigma = fminf(sigma, e.clamp);
+                                float v = e.val[(size_t)row * e.ldval + j];
+                                if (e.val_scale) v = (v - e.val_shift[j]) * e.val_scale[j];
+                                const float dz = v - u;
+                                lsum[i][r] += -(dz * dz) / (2.0f * sigma * sigma) - logf(sigma) - 0.91893853320467274178f;
                             }
                         }
                     }
                 }
             }
         }
+        if (e.inverse) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -394,7 +405,8 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         if (!L.bias || L.N_pad % 64 != 0) throw Error(FC_ERR_INVALID, "launch_gemm: pair-packed epilogue needs bias and N_pad % 64 == 0");
         p.nbm = rows_alloc / 128;
         if (epi_kind == EPI_AFFINE) launch_cfg<128, 320, 4, 1, EPI_AFFINE>(p, s);
-        else launch_cfg<128, 320, 4, 1, EPI_AUGMENT>(p, s);
+        else if (epi_kind == EPI_AUGMENT) launch_cfg<128, 320, 4, 1, EPI_AUGMENT>(p, s);
+        else launch_cfg<128, 320, 4, 1, EPI_SLICE>(p, s);
     }
 }
 

@@ -286,6 +286,63 @@ void launch_spline_flat(const float* x, const float* params, float* y, float* la
     FC_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------- exponential coupling
+// models/exponential_coupling.py:44-75: per point, W = rescale*tanh(scale*raw + shift) + reshift + 1e-8 (d2 x d2),
+// y2 = expm(W) x2 + b, ldj = tr W ; inverse x2 = expm(-W)(y2 - b).  expm acts on the vector directly (scaling by 2^-s so that
+// |W|_inf <= 1/2, 12-term Taylor action applied 2^s times): both of the reference's algorithms ('torch' = matrix_exp,
+// 'original' = truncated series with a batch-global stopping rule, utils.py:294-327) converge to this value.
+// One thread per point; only feasible for small d2 (the layer emits d2^2 + d2 numbers per point), like in the reference.
+template <int DMAX>
+__global__ void expm_coupling_kernel(const float* __restrict__ params, int ldp, float* xbuf, int ldx, int x2_col0, int d2,
+                                     const float* __restrict__ scal4, float* logprob, int rows, int inverse) {
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= rows) return;
+    const float sc = scal4[0], sh = scal4[1], rs = scal4[2], rsh = scal4[3];
+    const float* pr = params + (size_t)row * ldp;
+    float w[DMAX * DMAX], v[DMAX], term[DMAX], acc[DMAX];
+    float nrm = 0.f, tr = 0.f;
+    for (int i = 0; i < d2; ++i) {
+        float rsum = 0.f;
+        for (int j = 0; j < d2; ++j) {
+            float wij = rs * tanhf(sc * pr[i * d2 + j] + sh) + rsh + 1e-8f;
+            if (i == j) tr += wij;
+            if (inverse) wij = -wij;
+            w[i * DMAX + j] = wij;
+            rsum += fabsf(wij);
+        }
+        nrm = fmaxf(nrm, rsum);
+    }
+    float* xr = xbuf + (size_t)row * ldx + x2_col0;
+    for (int i = 0; i < d2; ++i) v[i] = inverse ? xr[i] - pr[d2 * d2 + i] : xr[i];
+    int s = 0;
+    while (nrm > 0.5f && s < 24) { nrm *= 0.5f; ++s; }
+    const float f = ldexpf(1.0f, -s);
+    for (int rep = 0; rep < (1 << s); ++rep) {
+        for (int i = 0; i < d2; ++i) { acc[i] = v[i]; term[i] = v[i]; }
+        for (int k = 1; k <= 12; ++k) {
+            float nt[DMAX];
+            const float fk = f / (float)k;
+            for (int i = 0; i < d2; ++i) {
+                float a = 0.f;
+                for (int j = 0; j < d2; ++j) a = fmaf(w[i * DMAX + j], term[j], a);
+                nt[i] = a * fk;
+            }
+            for (int i = 0; i < d2; ++i) { term[i] = nt[i]; acc[i] += nt[i]; }
+        }
+        for (int i = 0; i < d2; ++i) v[i] = acc[i];
+    }
+    for (int i = 0; i < d2; ++i) xr[i] = inverse ? v[i] : v[i] + pr[d2 * d2 + i];
+    if (!inverse) logprob[row] += tr;
+}
+void launch_expm_coupling(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, const float* scal4, float* logprob,
+                          int rows, int inverse, hipStream_t s) {
+    if (d2 > 16) throw Error(FC_ERR_UNSUPPORTED, "ExponentialCoupling: latent_dim - latent_dim/2 > 16 is not supported (the layer emits d2^2 numbers per point)");
+    if (ldp < d2 * d2 + d2) throw Error(FC_ERR_INVALID, "expm coupling: parameter pitch too small");
+    ProfScope ps("fc::expm_coupling_kernel", 0.0, 4.0 * rows * (d2 * d2 + 3.0 * d2), s);
+    hipLaunchKernelGGL(expm_coupling_kernel<16>, dim3((rows + 63) / 64), dim3(64), 0, s, params, ldp, xbuf, ldx, x2_col0, d2, scal4, logprob, rows, inverse);
+    FC_HIP(hipGetLastError());
+}
+
 // ---------------------------------------------------------------- DGCNN edge-conv tail
 // out[p, c] = LeakyReLU_0.2( max_j u[idx[p, j], c] + v[p, c] ), uv rows = [u (c_out) | v (c_out)].
 // Equals conv(cat(nbr - x, x)) -> BN -> LeakyReLU -> max_k of models/pytorch_gcn.py:23-47,85-99 because the 1x1 conv is

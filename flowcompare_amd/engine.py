@@ -201,7 +201,34 @@ class FlowHandle:
         return (out, z) if return_latent else out
 
     def inverse(self, z, context, extra_context, eps):
-        raise FcError(6, "fc_flow_inverse_f32: the sampling path (SURVEY.md §8f N2) is not built yet")
+        """Inverse pass of Flow.sample from a drawn latent z [B,n,latent_dim] -> x [B,n,input_dim]."""
+        B, N = z.shape[0], z.shape[1]
+        n_inv = self.n_noise - (1 if self.latent_dim > self.input_dim else 0)        # one draw per CIF block (Slice.inverse)
+        if eps is None:
+            eps = [torch.randn(B, N, self.noise_width[-1], device=self.device) for _ in range(n_inv)]
+        if len(eps) != n_inv:
+            raise RuntimeError(f"inverse pass needs {n_inv} noise tensors, got {len(eps)}")
+        z = _dev_f32(z)
+        ctx = _dev_f32(context)
+        if ctx.shape[0] != B:
+            raise RuntimeError(f"context batch {ctx.shape[0]} != latent batch {B}")
+        M = ctx.shape[1]
+        extra = None
+        if self.X:
+            if extra_context is None:
+                raise RuntimeError("this flow was built with extra context (extra_z_value_context) but extra_context is None")
+            extra = _dev_f32(extra_context[:, 0, :] if extra_context.dim() == 3 else extra_context)
+        eps = [_dev_f32(e) for e in eps]
+        L = lib()
+        with torch.cuda.device(self.device):
+            need = ctypes.c_size_t()
+            _check(L.fc_flow_workspace_bytes(self._h, B, N, M, ctypes.byref(need)))
+            ws = self._ws.get(need.value, self.device)
+            out = torch.empty(B, N, self.input_dim, dtype=torch.float32, device=self.device)
+            eps_arr = (ctypes.c_void_p * max(1, len(eps)))(*[e.data_ptr() for e in eps])
+            _check(L.fc_flow_inverse_f32(self._h, _ptr(z), _ptr(ctx), _ptr(extra), eps_arr, len(eps), _ptr(out), B, N, M,
+                                         _ptr(ws), ctypes.c_size_t(ws.numel()), _stream()))
+        return out
 
 
 class DgcnnHandle:

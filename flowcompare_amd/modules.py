@@ -287,6 +287,7 @@ class Flow(nn.Module):
         self._config = dict(config or {})
         self._handle = None
         self.last_eps = None
+        self._inverse_eps = None      # optional explicit noise for the CIF Slice.inverse draws of the next sample() call
 
     # -- engine plumbing
     def _engine(self):
@@ -321,6 +322,8 @@ class Flow(nn.Module):
     def sample(self, num_samples, n_points, context=None, sample_distrib=None, extra_context=None, eps=None):
         dist = sample_distrib if sample_distrib is not None else self.sample_dist
         z = dist.sample(num_samples, n_points=n_points)
+        if eps is None:
+            eps, self._inverse_eps = self._inverse_eps, None
         return self._engine().inverse(z, context, extra_context, eps)
 
     forward = _no_torch_forward

@@ -21,7 +21,7 @@ MEAN_ABS_TOL = 3e-4
 
 SUPPORTED = ["e2e_dulcet_L3", "e2e_c1_global_L2", "e2e_spline_L2", "e2e_affine_exp_L2", "e2e_tiny_affine", "e2e_tiny_spline_relu",
              "e2e_tiny_random_permute", "e2e_tiny_FullCombiner", "e2e_tiny_ExponentialCombiner", "e2e_tiny_global_extra",
-             "e2e_tiny_identity_aug"]
+             "e2e_tiny_identity_aug", "e2e_tiny_cif", "e2e_tiny_expcoupling", "e2e_tiny_expcoupling_orig"]
 
 
 def _build(fx):
@@ -72,6 +72,50 @@ def test_embedder_and_latent_match_reference_golden(name):
     assert np.abs(lp.cpu().double().numpy() - fx.a["log_prob_f64"]).max() < PER_POINT_TOL
 
 
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_make_sample_matches_reference_golden(name):
+    """Inverse / sampling path (models/transform.py:79-84) from the fixture's fixed latent z, through make_sample."""
+    fx = Fixture(name)
+    cfg, md = _build(fx)
+
+    class FixedZ:
+        def sample(self, num_samples, n_points=None, context=None):
+            return fx.t("sample_z").float().to(DEV)
+
+    inv_eps = [e.to(DEV) for e in fx.eps(prefix="inveps")]
+    md["flow"]._inverse_eps = inv_eps or None
+    extra = fx.t("extra")
+    x = fa.make_sample(24, fx.t("extract_0")[:1].to(DEV), md, cfg, sample_distrib=FixedZ(),
+                       extra_context=None if extra is None else extra[:1].to(DEV))
+    d = np.abs(x.cpu().double().numpy() - fx.a["sample_x_f64"])
+    scale = max(1.0, float(np.abs(fx.a["sample_x_f64"]).max()))     # e2e_tiny_cif's random-weight inverse reaches |x| ~ 6e4
+    print(f"{name}: sample max err {d.max():.2e} (|x|max {scale:.1f})")
+    assert d.max() < 5e-4 * scale
+
+
+def test_inverse_roundtrip_real_dims():
+    """forward(inverse(z)) latent == z at the real dims (invertibility: free property of the domain)."""
+    fx = Fixture("e2e_dulcet_L3")
+    cfg, md = _build(fx)
+    h = md["flow"]._engine()
+    ctx = torch.from_numpy(fx.a["emb_f64"]).float().to(DEV)
+    extra = fx.t("extra").to(DEV)
+    g = torch.Generator().manual_seed(0)
+    z = (torch.randn(2, 64, 300, generator=g) * 0.6).to(DEV)
+    x = h.inverse(z, ctx, extra, None)
+    assert x.shape == (2, 64, 6) and torch.isfinite(x).all()
+    # the augmenter discards 294 dims, so check invertibility on the transforms after it: log_prob's latent of x differs from z,
+    # but inverse must be deterministic and finite; exact round trip is checked on the identity-augmenter fixture below
+    fx2 = Fixture("e2e_tiny_identity_aug")
+    cfg2, md2 = _build(fx2)
+    h2 = md2["flow"]._engine()
+    ctx2 = torch.from_numpy(fx2.a["emb_f64"]).float().to(DEV)
+    z2 = (torch.randn(2, 20, 6, generator=g) * 0.6).to(DEV)
+    x2 = h2.inverse(z2, ctx2[:, :24], None, None)
+    _, zz = h2.log_prob(x2, ctx2[:, :24], None, [], return_latent=True)
+    assert (zz - z2).abs().max().item() < 2e-4
+
+
 def test_matches_oracle_on_fresh_seeded_inputs():
     """HIP path vs the pinned oracle on inputs no fixture contains (module-initialised weights, torch RNG)."""
     cfg = fa.named_config("c4_dgcnn_attn_extra_affine", n_flow_layers=4, sample_size=200)
@@ -105,15 +149,12 @@ def test_scene_independence_and_determinism():
 
 
 def test_unsupported_and_bad_arguments_fail_loudly():
-    fx = Fixture("e2e_tiny_cif")
-    cfg = dict(fx.cfg)
-    md = fa.initialize_flow(cfg, device=DEV, mode="test")
-    x = fx.t("extract_1").to(DEV)
-    with pytest.raises(RuntimeError, match="CIFblock"):
-        md["flow"].log_prob(x, context=torch.zeros(2, 24, 10, device=DEV))
     fx = Fixture("e2e_tiny_affine")
     cfg, md = _build(fx)
     with pytest.raises(RuntimeError, match="extra"):
         md["flow"].log_prob(fx.t("extract_1").to(DEV), context=torch.zeros(3, 24, 10, device=DEV), extra_context=None)
     with pytest.raises(RuntimeError, match="n_neighbors|fewer"):
         md["input_embedder"](torch.rand(1, 5, 6, device=DEV))
+    with pytest.raises(RuntimeError, match="noise"):
+        md["flow"].log_prob(fx.t("extract_1").to(DEV), context=torch.zeros(3, 24, 10, device=DEV),
+                            extra_context=torch.zeros(3, 20, 1, device=DEV), eps=[])
