@@ -24,6 +24,7 @@ EXPORTS = [
     "fc_flow_create", "fc_flow_destroy", "fc_flow_workspace_bytes", "fc_flow_noise_count", "fc_flow_noise_width",
     "fc_flow_logprob_f32", "fc_flow_inverse_f32",
     "fc_dgcnn_create", "fc_dgcnn_destroy", "fc_dgcnn_out_dim", "fc_dgcnn_workspace_bytes", "fc_dgcnn_embed_f32",
+    "fc_paconv_create", "fc_paconv_destroy", "fc_paconv_out_dim", "fc_paconv_workspace_bytes", "fc_paconv_embed_f32", "fc_op_fps_f32",
     "fc_profile_enable", "fc_profile_reset", "fc_profile_report",
     "fc_op_linear_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
 ]
@@ -60,6 +61,7 @@ def lib():
         L.fc_last_error.restype = ctypes.c_char_p
         L.fc_flow_destroy.restype = None
         L.fc_dgcnn_destroy.restype = None
+        L.fc_paconv_destroy.restype = None
         if L.fc_abi_version() != ABI_VERSION:
             raise RuntimeError("libfcflow.so ABI version mismatch: rebuild with `python -m flowcompare_amd.build --force`")
         _lib = L
@@ -267,7 +269,50 @@ class DgcnnHandle:
         return out
 
 
+class PaconvHandle:
+    """fc_paconv wrapper: replaces models.PointNet2SSGSeg.forward (reference pointnet2_paconv_seg.py:63-82)."""
+
+    def __init__(self, state_dict, version, device):
+        self.version = version
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("flowcompare_amd: the embedder must be on a HIP device (`.to('cuda')`); there is no CPU path")
+        arr, keep = _tensor_table(state_dict)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(lib().fc_paconv_create(arr, len(arr), ctypes.byref(self._h)))
+        del keep
+        self.out_dim = lib().fc_paconv_out_dim(self._h)
+        self._ws = _Workspace()
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.fc_paconv_destroy(self._h)
+            self._h = None
+
+    def embed(self, pts):
+        pts = _dev_f32(pts)
+        B, M = pts.shape[0], pts.shape[1]
+        L = lib()
+        with torch.cuda.device(self.device):
+            need = ctypes.c_size_t()
+            _check(L.fc_paconv_workspace_bytes(self._h, B, M, ctypes.byref(need)))
+            ws = self._ws.get(need.value, self.device)
+            out = torch.empty(B, M, self.out_dim, dtype=torch.float32, device=self.device)
+            _check(L.fc_paconv_embed_f32(self._h, _ptr(pts), _ptr(out), B, M, _ptr(ws), ctypes.c_size_t(ws.numel()), _stream()))
+        return out
+
+
 # ---------------------------------------------------------------- single operators (unit-level parity tests)
+def op_fps(xyz, m):
+    xyz = _dev_f32(xyz)
+    B, n, _ = xyz.shape
+    idx = torch.empty(B, m, dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _check(lib().fc_op_fps_f32(_ptr(xyz), _ptr(idx), B, n, m, _stream()))
+    return idx
+
+
 def op_linear(x, W, bias=None, residual=None, act="none"):
     code = {"none": 0, "gelu": 1, "relu": 2, "elu": 3, "lrelu": 4}[act]
     x, W = _dev_f32(x), _dev_f32(W)

@@ -120,7 +120,7 @@ def initialize_flow(config, device="cuda", mode="train"):
         input_embedder = M.DGCNNembedderGlobal(input_dim=Din, out_mlp_dims=config["hidden_dims_embedder_out"],
                                                n_neighbors=config["n_neighbors"], emb_dim=config["input_embedding_dim"])
     elif emb == "PAConv":
-        raise NotImplementedError("flowcompare_amd: the PAConv embedder (SURVEY.md §8 a18) is not built yet")
+        input_embedder = M.PointNet2SSGSeg(c=Din - 3, k=config["input_embedding_dim"], out_mlp_dims=config["hidden_dims_embedder_out"])
     elif emb == "idenity":                      # sic, model_initialization.py:173
         input_embedder = nn.Identity()
     else:

@@ -21,6 +21,10 @@ Reference classes mirrored (file:line in the reference repo):
   Augment / AugmentAttentionPreconditioner           models/augmenter.py:7-67
   Slice                            models/slice.py:7-58
   DGCNNembedder / DGCNNembedderGlobal                models/pytorch_gcn.py:50-188
+  PointNet2SSGSeg (PAConv embedder)                  models/scene_seg_PAConv/model/pointnet2/pointnet2_paconv_seg.py:14-82
+    PointNet2SAModule / PointNet2FPModule            .../pointnet2_paconv_modules.py:64-238
+    PAConv / ScoreNet / SharedPAConv                 .../paconv.py:12-260
+    SharedMLP / Conv2d                               models/scene_seg_PAConv/util/block.py:14-150
 """
 import math
 
@@ -375,3 +379,95 @@ class DGCNNembedderGlobal(_DGCNNBase):
         self.n_neighbors, self.input_dim = n_neighbors, input_dim
         self._build_trunk(input_dim)
         self.out_mlp = MLP(1024, out_mlp_dims, emb_dim)
+
+
+# ------------------------------------------------------------------ PAConv embedder (PointNet++ SSG U-Net)
+class ScoreNet(_Container):
+    def __init__(self, in_channel, out_channel, hidden_unit):
+        super().__init__()
+        dims = [in_channel] + list(hidden_unit) + [out_channel]
+        self.mlp_convs_hidden = nn.ModuleList()
+        self.mlp_bns_hidden = nn.ModuleList()
+        for i in range(1, len(dims)):
+            conv = nn.Conv2d(dims[i - 1], dims[i], 1, bias=i == len(dims) - 1)      # last_bn False -> only the last conv has a bias
+            nn.init.xavier_normal_(conv.weight)
+            if conv.bias is not None:
+                nn.init.constant_(conv.bias, 0)
+            self.mlp_convs_hidden.append(conv)
+            self.mlp_bns_hidden.append(nn.BatchNorm2d(dims[i]))
+
+
+class PAConv(_Container):
+    def __init__(self, input_dim, output_dim, m=8, hidden=(16,)):
+        super().__init__()
+        self.input_dim, self.output_dim, self.m = input_dim, output_dim, m
+        self.bn = nn.BatchNorm2d(output_dim, momentum=0.1)
+        self.scorenet = ScoreNet(3, m, list(hidden))
+        bank = nn.init.kaiming_normal_(torch.empty(m, input_dim * 2, output_dim))
+        self.weightbank = nn.Parameter(bank.permute(1, 0, 2).reshape(input_dim * 2, m * output_dim).contiguous())
+
+
+class _Grouper(_Container):
+    pass
+
+
+class PointNet2SAModule(_Container):
+    def __init__(self, mlp, nsample=32):
+        super().__init__()
+        self.nsample = nsample
+        self.groupers = nn.ModuleList([_Grouper()])
+        spec = list(mlp)
+        spec[0] += 3                                                    # use_xyz
+        self.mlps = nn.ModuleList([nn.Sequential()])
+        for i in range(len(spec) - 1):
+            self.mlps[0].add_module(f"layer{i}", PAConv(spec[i], spec[i + 1]))
+
+
+class _BN2dWrap(nn.Sequential):
+    def __init__(self, c):
+        super().__init__()
+        self.add_module("bn", nn.BatchNorm2d(c))
+
+
+class _ConvBNReLU(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        conv = nn.Conv2d(cin, cout, kernel_size=(1, 1), bias=False)
+        nn.init.kaiming_normal_(conv.weight)
+        self.add_module("conv", conv)
+        self.add_module("bn", _BN2dWrap(cout))
+        self.add_module("activation", nn.ReLU(inplace=True))
+
+
+class PointNet2FPModule(_Container):
+    def __init__(self, mlp):
+        super().__init__()
+        self.mlp = nn.Sequential()
+        for i in range(len(mlp) - 1):
+            self.mlp.add_module(f"layer{i}", _ConvBNReLU(mlp[i], mlp[i + 1]))
+
+
+class PointNet2SSGSeg(nn.Module):
+    """PAConv context embedder: 4 set-abstraction levels (FPS to n/4, 32-NN grouping, 3 PAConv layers, max) + 4 feature
+    propagation levels (3-NN inverse-distance interpolation, skip concat, shared MLP) + head MLP."""
+
+    def __init__(self, c=3, k=13, use_xyz=True, out_mlp_dims=(512, 512, 512), args=None):
+        super().__init__()
+        sa = [[c, 32, 32, 64], [64, 64, 64, 128], [128, 128, 128, 256], [256, 256, 256, 512]]
+        fp = [[128 + c, 128, 128, 128], [256 + 64, 256, 128], [256 + 128, 256, 256], [512 + 256, 256, 256]]
+        self.SA_modules = nn.ModuleList(PointNet2SAModule(m) for m in sa)
+        self.FP_modules = nn.ModuleList(PointNet2FPModule(m) for m in fp)
+        self.out_mlp = MLP(128, list(out_mlp_dims), k)
+        self._handle = None
+
+    def _engine(self):
+        if self.training:
+            raise RuntimeError("flowcompare_amd: the HIP PAConv embedder implements eval-mode BatchNorm only; call .eval()")
+        key = _engine.params_version(self)
+        if self._handle is None or self._handle.version != key:
+            self._handle = _engine.PaconvHandle(self.state_dict(), key, next(self.parameters()).device)
+        return self._handle
+
+    def forward(self, pointcloud):
+        """pointcloud [B,M,3+c] (xyz first) -> [B,M,k]."""
+        return self._engine().embed(pointcloud)

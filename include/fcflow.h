@@ -75,6 +75,7 @@ typedef struct fc_flow_config {
 
 typedef struct fc_flow fc_flow;      /* replaces models.Flow (models/transform.py:61-84)         */
 typedef struct fc_dgcnn fc_dgcnn;    /* replaces models.DGCNNembedder(Global) (models/pytorch_gcn.py:50-188) */
+typedef struct fc_paconv fc_paconv;  /* replaces models.PointNet2SSGSeg (models/scene_seg_PAConv/model/pointnet2/pointnet2_paconv_seg.py:14-82) */
 
 int fc_abi_version(void);
 const char* fc_last_error(void);     /* thread-local, valid until the next failing call on this thread */
@@ -121,6 +122,21 @@ int fc_dgcnn_workspace_bytes(const fc_dgcnn* emb, int32_t B, int32_t M, size_t* 
 /* pts [B,M,C_in] -> out [B,M,E] (per-point) or [B,E] (global_pool); eval-mode BatchNorm (running stats). */
 int fc_dgcnn_embed_f32(fc_dgcnn* emb, const float* pts, float* out, int32_t B, int32_t M,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- PAConv context embedder: input_embedder(extract_0) for config['input_embedder'] == 'PAConv' ------------------ */
+/* Weights = PointNet2SSGSeg.state_dict().  Includes native replacements of the six pointops_cuda kernels the reference uses on
+ * this path (furthestsampling, gathering, knnquery_heap, grouping, nearestneighbor, interpolation:
+ * models/scene_seg_PAConv/lib/pointops/src/pointops_api.cpp:16-40). */
+int fc_paconv_create(const fc_tensor* tensors, int32_t n_tensors, fc_paconv** out);
+void fc_paconv_destroy(fc_paconv* emb);
+int fc_paconv_out_dim(const fc_paconv* emb);
+int fc_paconv_workspace_bytes(const fc_paconv* emb, int32_t B, int32_t M, size_t* bytes);
+/* pts [B,M,3+c] (xyz first) -> out [B,M,E]; needs M >= 256 (four 4x down-samplings); eval-mode BatchNorm. */
+int fc_paconv_embed_f32(fc_paconv* emb, const float* pts, float* out, int32_t B, int32_t M,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* furthest point sampling alone (lib/pointops/src/sampling/sampling_cuda_kernel.cu:58-168): xyz [B,n,3] -> idx [B,m] int32.
+ * Also the FPS subsampling step of the data loader that feeds the path. */
+int fc_op_fps_f32(const float* xyz, int32_t* idx, int32_t B, int32_t n, int32_t m, void* stream);
 
 /* ---- in-library kernel timing (used by bench.py for the roofline object) --------------------- */
 /* When enabled, every kernel launch of this library is bracketed by HIP events on its launch stream.

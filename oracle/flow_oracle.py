@@ -479,6 +479,14 @@ def dgcnn_embed(cfg, sd, pts):
     return mlp(sd, "out_mlp", t, F.gelu)
 
 
+def context_embed(cfg, sd, pts):
+    """input_embedder dispatch of model_initialization.py:162-176."""
+    if cfg["input_embedder"] == "PAConv":
+        from . import paconv_oracle
+        return paconv_oracle.paconv_embed(sd, pts)
+    return dgcnn_embed(cfg, sd, pts)
+
+
 # --------------------------------------------------------------------------- the boundary function
 def inner_loop(cfg, sd_flow, sd_emb, batch, eps=()):
     """model_initialization.py:206-228 -> (loss, log_prob[B,N], bpd)."""
@@ -489,7 +497,7 @@ def inner_loop(cfg, sd_flow, sd_emb, batch, eps=()):
         if cfg["sample_size"] != e1.shape[1]:
             raise RuntimeError("extra_context is repeated to config['sample_size'], which must equal N")
         extra = extra[:, None, :].expand(-1, cfg["sample_size"], -1)
-    emb = dgcnn_embed(cfg, sd_emb, e0)
+    emb = context_embed(cfg, sd_emb, e0)
     if emb.dim() == 2:
         emb = emb[:, None, :].expand(-1, e1.shape[1], -1)
     lp = flow_log_prob(cfg, sd_flow, e1, emb, extra, eps)
@@ -500,7 +508,7 @@ def inner_loop(cfg, sd_flow, sd_emb, batch, eps=()):
 def make_sample(cfg, sd_flow, sd_emb, z, extract_0, extra=None, eps=()):
     """model_initialization.py:231-245 with the latent z [1,n,D] supplied by the caller."""
     n = z.shape[1]
-    emb = dgcnn_embed(cfg, sd_emb, extract_0[..., : cfg["input_dim"]])
+    emb = context_embed(cfg, sd_emb, extract_0[..., : cfg["input_dim"]])
     if emb.dim() == 2:
         emb = emb[:, None, :].expand(-1, n, -1)
     if extra is not None:

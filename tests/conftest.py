@@ -92,7 +92,7 @@ def _constructor_value(name, shape):
     return torch.zeros(shape)                   # base_dist.buffer, sample_dist.loc, std_normal.buffer
 
 
-E2E_REAL = ["e2e_dulcet_L3", "e2e_c1_global_L2", "e2e_spline_L2", "e2e_affine_exp_L2"]
+E2E_REAL = ["e2e_dulcet_L3", "e2e_c1_global_L2", "e2e_spline_L2", "e2e_affine_exp_L2", "e2e_paconv_L2"]
 E2E_TINY = ["e2e_tiny_affine", "e2e_tiny_spline_relu", "e2e_tiny_expcoupling", "e2e_tiny_expcoupling_orig", "e2e_tiny_cif",
             "e2e_tiny_random_permute", "e2e_tiny_FullCombiner", "e2e_tiny_ExponentialCombiner", "e2e_tiny_global_extra",
             "e2e_tiny_identity_aug"]

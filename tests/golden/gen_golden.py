@@ -257,8 +257,44 @@ def spline_case():
                         x_inv=npy(xi), logabsdet_inv=npy(ldi), y_f32=npy(y32), logabsdet_f32=npy(ld32)))
 
 
+def patch_pointops():
+    """The six CUDA kernels of the PAConv embedder cannot run here: substitute the oracle's CPU restatements
+    INTO the reference so that its own Python (PointNet2SSGSeg, QueryAndGroup, PAConv, ScoreNet, FP modules) runs on CPU."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import paconv_oracle as P
+    from models.scene_seg_PAConv.lib.pointops.functions import pointops
+    pointops.furthestsampling = lambda xyz, m: P.furthest_sampling(xyz, m).int()
+    pointops.gathering = lambda feat, idx: P.gathering(feat, idx.long())
+    pointops.knnquery_heap = lambda nsample, xyz, new_xyz: P.knnquery_heap(nsample, xyz, new_xyz).int()
+    pointops.grouping = lambda feat, idx: P.grouping(feat, idx.long())
+    pointops.nearestneighbor = lambda unknown, known: P.nearest_neighbor3(unknown, known)
+    pointops.interpolation = lambda feat, idx, w: P.interpolation(feat, idx.long(), w)
+
+
+def paconv_embedder_case():
+    """PAConv embedder alone: point counts 320 -> 80 -> 20 -> 5 -> 1 exercise n < nsample (heap slots left at index 0) and a
+    single known point in feature propagation."""
+    name = "emb_paconv"
+    cfg = load_cfg("summer-terrain", sample_size=64, n_flow_layers=1)
+    pts = synth.synth_points(name + "/pts", 2, 320, 31)
+    arrays = dict(pts=npy(pts))
+    for tag, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+        md = build(dict(cfg), 31, dtype)
+        with torch.no_grad():
+            emb = md["input_embedder"](pts.to(dtype))
+        arrays[f"emb_{tag}"] = npy(emb)
+        if tag == "f64":
+            keys = {k: {n: list(v.shape) for n, v in md[k].state_dict().items()} for k in ("flow", "input_embedder")}
+            arrays["sd_keys_json"] = np.frombuffer(json.dumps(keys).encode(), dtype=np.uint8)
+    print(f"[{name}] f32-vs-f64 max {np.abs(arrays['emb_f64'] - arrays['emb_f32']).max():.2e}")
+    save(name, cfg, arrays, meta=dict(B=2, M=320, seed=31))
+
+
 def main():
     torch.set_num_threads(8)
+    patch_pointops()
+    paconv_embedder_case()
+    e2e_case("e2e_paconv_L2", "summer-terrain", dict(n_flow_layers=2), B=2, N=48, M=256, seed=32)
     # ---- real-dims end-to-end slices (few layers)
     e2e_case("e2e_dulcet_L3", "dulcet-universe", dict(n_flow_layers=3), B=2, N=64, M=80, seed=11)
     e2e_case("e2e_c1_global_L2", "helpful-sponge", dict(n_flow_layers=2), B=2, N=64, M=64, seed=12)

@@ -90,6 +90,9 @@ def synth_tensor(name: str, ref: torch.Tensor, seed: int = 0) -> torch.Tensor:
     elif leaf == "w" and len(shape) == 2:                    # Full/ExponentialCombiner
         d = shape[0]
         v = uniform(name, shape, -1.0, 1.0, seed) * (0.5 / np.sqrt(d)) + np.eye(d) * 0.9
+    elif leaf == "weightbank":                               # PAConv [2*C_in, m*C_out]
+        a = 1.6 / np.sqrt(shape[0])
+        v = uniform(name, shape, -a, a, seed)
     elif leaf == "weight" and len(shape) >= 2:
         fan_in = int(np.prod(shape[1:]))
         a = 1.6 / np.sqrt(fan_in)

@@ -21,7 +21,7 @@ MEAN_ABS_TOL = 3e-4
 
 SUPPORTED = ["e2e_dulcet_L3", "e2e_c1_global_L2", "e2e_spline_L2", "e2e_affine_exp_L2", "e2e_tiny_affine", "e2e_tiny_spline_relu",
              "e2e_tiny_random_permute", "e2e_tiny_FullCombiner", "e2e_tiny_ExponentialCombiner", "e2e_tiny_global_extra",
-             "e2e_tiny_identity_aug", "e2e_tiny_cif", "e2e_tiny_expcoupling", "e2e_tiny_expcoupling_orig"]
+             "e2e_tiny_identity_aug", "e2e_tiny_cif", "e2e_tiny_expcoupling", "e2e_tiny_expcoupling_orig", "e2e_paconv_L2"]
 
 
 def _build(fx):

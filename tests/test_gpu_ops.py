@@ -120,3 +120,38 @@ def test_spline_golden_forward_and_inverse():
     # tails: identity with zero log-det, knots: +-3 inclusive
     out = (x.abs() > 3)
     assert torch.equal(y.cpu()[out], x[out]) and (lad.cpu()[out] == 0).all()
+
+
+@pytest.mark.parametrize("B,n,m", [(2, 1024, 256), (1, 4096, 1024), (3, 300, 75), (1, 20, 5), (2, 64, 64)])
+def test_fps_matches_restatement(B, n, m):
+    """Farthest point sampling vs the CPU restatement of the reference's CUDA kernel (same start index, same min-distance update,
+    same arg-max tie rule); bit-exact integer output."""
+    from oracle import paconv_oracle as P
+    xyz = _rand(B, n, 3, seed=11)
+    idx = engine.op_fps(xyz.to(DEV), m).cpu().long()
+    ref = P.furthest_sampling(xyz, m)
+    assert torch.equal(idx, ref)
+
+
+def test_fps_ties_on_a_grid():
+    """A regular grid produces exact distance ties: the winner must follow the kernel's (k mod T, k) rule, not 'lowest index'."""
+    from oracle import paconv_oracle as P
+    g = torch.stack(torch.meshgrid(torch.arange(8.), torch.arange(8.), torch.arange(4.), indexing="ij"), -1).reshape(1, -1, 3)
+    idx = engine.op_fps(g.to(DEV), 64).cpu().long()
+    assert torch.equal(idx, P.furthest_sampling(g, 64))
+
+
+def test_paconv_embedder_matches_reference_golden():
+    """PAConv U-Net (320 -> 80 -> 20 -> 5 -> 1 points: n < nsample heap tails, single known point in FP) vs the golden produced
+    by the reference's own Python with the pointops kernels substituted by their CPU restatements."""
+    import flowcompare_amd as fa
+    from conftest import Fixture
+    fx = Fixture("emb_paconv")
+    cfg = dict(fx.cfg)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    _, sd_emb = fx.state_dicts()
+    md["input_embedder"].load_state_dict(sd_emb)
+    emb = md["input_embedder"](fx.t("pts").to(DEV)).cpu().double().numpy()
+    d = np.abs(emb - fx.a["emb_f64"])
+    print(f"paconv embedder: max {d.max():.2e} mean {d.mean():.2e}")
+    assert d.max() < 2e-5

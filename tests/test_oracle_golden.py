@@ -19,7 +19,7 @@ def test_forward_fp64_matches_reference(name):
     sd_flow, sd_emb = fx.state_dicts(torch.float64)
     e0, e1, ex = _batch(fx, torch.float64)
     with torch.no_grad():
-        emb = O.dgcnn_embed(cfg, sd_emb, e0)
+        emb = O.context_embed(cfg, sd_emb, e0)
         np.testing.assert_allclose(emb.numpy(), fx.a["emb_f64"], rtol=1e-9, atol=1e-9)
         loss, lp, bpd = O.inner_loop(cfg, sd_flow, sd_emb, (e0, e1, ex), fx.eps(torch.float64))
     np.testing.assert_allclose(lp.numpy(), fx.a["log_prob_f64"], rtol=1e-9, atol=1e-8)
@@ -35,7 +35,7 @@ def test_per_transform_records_fp64(name):
     e0, e1, ex = _batch(fx, torch.float64)
     rec = []
     with torch.no_grad():
-        emb = O.dgcnn_embed(cfg, sd_emb, e0)
+        emb = O.context_embed(cfg, sd_emb, e0)
         if emb.dim() == 2:
             emb = emb[:, None, :].expand(-1, e1.shape[1], -1)
         extra = None if ex is None else ex[:, None, :].expand(-1, e1.shape[1], -1)
@@ -99,3 +99,40 @@ def test_knn_op_fixture():
         same = (idx32.sort(-1)[0] == ref32.sort(-1)[0]).all(-1)
         margin = torch.from_numpy(z[f"{tag}_margin_f64"])
         assert (same | (margin < 1e-5)).all()                    # only near-ties at the k-th boundary may differ
+
+
+def test_paconv_embedder_fixture():
+    """PAConv U-Net restatement vs the reference's own Python run on CPU (with the six CUDA pointops kernels substituted by
+    oracle/paconv_oracle.py's restatements: those six are pinned only by restatement, see that file's header)."""
+    from oracle import paconv_oracle as P
+    fx = Fixture("emb_paconv")
+    _, sd_emb = fx.state_dicts(torch.float64)
+    with torch.no_grad():
+        emb = P.paconv_embed(sd_emb, fx.t("pts", torch.float64))
+    np.testing.assert_allclose(emb.numpy(), fx.a["emb_f64"], rtol=1e-9, atol=1e-9)
+    _, sd32 = fx.state_dicts(torch.float32)
+    with torch.no_grad():
+        emb32 = P.paconv_embed(sd32, fx.t("pts", torch.float32))
+    assert np.abs(emb32.numpy() - fx.a["emb_f64"]).max() < 1e-5
+
+
+def test_pointops_restatements_basic_properties():
+    from oracle import paconv_oracle as P
+    g = torch.Generator().manual_seed(0)
+    xyz = torch.rand(2, 200, 3, generator=g)
+    idx = P.furthest_sampling(xyz, 50)
+    assert (idx[:, 0] == 0).all() and all(len(set(r.tolist())) == 50 for r in idx)          # starts at 0, no repeats
+    d = torch.cdist(xyz, xyz)
+    for b in range(2):                                                                       # greedy max-min property
+        chosen = [0]
+        for j in range(1, 50):
+            mind = d[b][:, chosen].min(1)[0]
+            assert abs(float(mind[idx[b, j]]) - float(mind.max())) < 1e-6
+            chosen.append(int(idx[b, j]))
+    q = xyz[:, :7]
+    nn = P.knnquery_heap(32, xyz, q)
+    assert (nn[:, :, 0] == torch.arange(7)).all()                                            # a point is its own nearest neighbour
+    nn_small = P.knnquery_heap(32, xyz[:, :5], q[:, :2])
+    assert (nn_small[..., 5:] == 0).all()                                                    # unfilled heap slots keep index 0
+    dist, i3 = P.nearest_neighbor3(xyz, xyz[:, :1])
+    assert torch.isinf(dist[..., 1:]).all() and (i3 == 0).all()                              # fewer than 3 known points
