@@ -74,6 +74,8 @@ struct PackedLinear {
     float* W = nullptr;        // [N_alloc][K_pad] row-major, zero padded
     float* bias = nullptr;     // [N_alloc]
     float* colvec = nullptr;   // [N_alloc] or null: rank-1 term  C += rowscal[row] * colvec[n]
+    unsigned short* W3 = nullptr;  // the same matrix as 3 bf16 limbs, [N_alloc][K_pad/16][3][16]: x = hi + mid + lo exactly to 24 bits
+                                   // (operand image of the split-bf16 GEMM variant, see gemm.hip)
     int N_pad = 0;             // columns written (multiple of 32)
     int K_pad = 0;             // multiple of 32 (sum of segment widths)
     int seg_k[3] = {0, 0, 0};  // padded K of each A segment

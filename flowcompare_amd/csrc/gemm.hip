@@ -19,6 +19,8 @@
 namespace fc {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct GemmParams {
     const float* A[3];
@@ -26,6 +28,7 @@ struct GemmParams {
     int kt[3];          // 32-wide k tiles per segment
     int KT;             // total k tiles
     const float* W;     // [N_pad][K_pad]
+    const unsigned short* W3;   // bf16 limb image [n_alloc][K_pad/16][3][16] (split-bf16 variant)
     int K_pad;
     const float* bias;
     const float* colvec;
@@ -184,6 +187,91 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
         }
     }
 
+    if constexpr (VAR == 3) {
+        // ================= split-bf16 main loop: fp32-equivalent products on the bf16 matrix cores =================
+        // x = hi + mid + lo (three bf16 limbs, 24 significant bits);  a*b ~= ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh),
+        // the dropped terms are below 2^-24 |a b|.  Every limb product is exact in the MFMA's fp32 accumulator, so the result
+        // has fp32-GEMM accuracy (profiles/micro: 6e-9 rel. error with exact accumulation) at 6 bf16 MFMAs (32 cycles each)
+        // per 32x32x16 block instead of 8 fp32 MFMAs (64 cycles each): 2.67x the matrix rate.  Weights are pre-split on the host
+        // (PackedLinear.W3); activations are split while they are staged into LDS.  K tile = 16, LDS row = 3 limbs x 32 B + 16 B pad.
+        constexpr int ROWB = 112;                                   // bytes per LDS row
+        constexpr int STAGE3 = (BM + BN) * ROWB;
+        constexpr int A3 = BM / 64, W3N = BN * 6 / 256;            // float4 loads of A, 16-byte loads of W per thread and tile
+        char* smc = reinterpret_cast<char*>(smem);
+        const int lrow3 = tid >> 2, lc3 = (tid & 3) * 4;
+        const int KT16 = p.KT * 2;
+        float4 ra3[A3];
+        uint4 rw3[W3N];
+#define FC_GLOAD3(KT_)                                                                                             \
+        {                                                                                                          \
+            const float* Ap_ = p.A[0];                                                                             \
+            int lda_ = p.lda[0], kk_ = (KT_);                                                                      \
+            if (kk_ >= 2 * p.kt[0]) {                                                                              \
+                kk_ -= 2 * p.kt[0]; Ap_ = p.A[1]; lda_ = p.lda[1];                                                 \
+                if (kk_ >= 2 * p.kt[1]) { kk_ -= 2 * p.kt[1]; Ap_ = p.A[2]; lda_ = p.lda[2]; }                     \
+            }                                                                                                      \
+            const float* a_ = Ap_ + (size_t)(m0 + lrow3) * lda_ + kk_ * 16 + lc3;                                  \
+            _Pragma("unroll") for (int i = 0; i < A3; ++i) ra3[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(64 * i) * lda_); \
+            _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
+                const int c_ = tid + 256 * i, row_ = c_ / 6, part_ = c_ - row_ * 6;                                \
+                rw3[i] = *reinterpret_cast<const uint4*>(p.W3 + ((size_t)(n0 + row_) * KT16 + (KT_)) * 48 + part_ * 8); \
+            }                                                                                                      \
+        }
+#define FC_LSTORE3(ST_)                                                                                            \
+        {                                                                                                          \
+            char* sa_ = smc + (ST_) * STAGE3 + lrow3 * ROWB + (tid & 3) * 8;                                        \
+            _Pragma("unroll") for (int i = 0; i < A3; ++i) {                                                       \
+                const float x_[4] = {ra3[i].x, ra3[i].y, ra3[i].z, ra3[i].w};                                      \
+                bf16x4 h_, m_, l_;                                                                                 \
+                _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                 \
+                    h_[e_] = (__bf16)x_[e_];                                                                       \
+                    const float r1_ = x_[e_] - (float)h_[e_];                                                      \
+                    m_[e_] = (__bf16)r1_;                                                                          \
+                    l_[e_] = (__bf16)(r1_ - (float)m_[e_]);                                                        \
+                }                                                                                                  \
+                *reinterpret_cast<bf16x4*>(sa_ + 64 * i * ROWB) = h_;                                               \
+                *reinterpret_cast<bf16x4*>(sa_ + 64 * i * ROWB + 32) = m_;                                          \
+                *reinterpret_cast<bf16x4*>(sa_ + 64 * i * ROWB + 64) = l_;                                          \
+            }                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
+                const int c_ = tid + 256 * i, row_ = c_ / 6, part_ = c_ - row_ * 6;                                \
+                *reinterpret_cast<uint4*>(smc + (ST_) * STAGE3 + (BM + row_) * ROWB + part_ * 16) = rw3[i];          \
+            }                                                                                                      \
+        }
+        FC_GLOAD3(0)
+        FC_LSTORE3(0)
+        __syncthreads();
+        for (int kt = 0; kt < KT16; ++kt) {
+            const int ktn = kt + 1 < KT16 ? kt + 1 : kt;
+            FC_GLOAD3(ktn)
+            const char* sA = smc + (kt & 1) * STAGE3 + (wr * TM * 32 + li) * ROWB + lh * 16;
+            const char* sB = smc + (kt & 1) * STAGE3 + (BM + wc * TN * 32 + li) * ROWB + lh * 16;
+            bf16x8 af3[TM][3], bf3[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) af3[i][q] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * ROWB + q * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bf3[j][q] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * ROWB + q * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][2], bf3[j][0], acc[i][j], 0, 0, 0);   // lo * hi
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][1], bf3[j][1], acc[i][j], 0, 0, 0);   // mid * mid
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][0], bf3[j][2], acc[i][j], 0, 0, 0);   // hi * lo
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][1], bf3[j][0], acc[i][j], 0, 0, 0);   // mid * hi
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][0], bf3[j][1], acc[i][j], 0, 0, 0);   // hi * mid
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][0], bf3[j][0], acc[i][j], 0, 0, 0);   // hi * hi
+                }
+            FC_LSTORE3((kt + 1) & 1)
+            __syncthreads();
+        }
+#undef FC_GLOAD3
+#undef FC_LSTORE3
+    } else {
     // ---- global -> register staging: thread t moves float4 (t&7) of rows (t>>3) + 32*i.  Straight-line code on plain
     //      register arrays (no lambdas / conditionals around them: those sent the staging tile through scratch memory).
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
@@ -255,6 +343,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
 #undef FC_GLOAD
 #undef FC_LSTORE
+
+    }
 
     // ------------------------------------------------------------------ epilogues
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15
@@ -345,11 +435,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 2, g_gemm_stagger = 0, g_gemm_colgroup = 10;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 3, g_gemm_stagger = 0, g_gemm_colgroup = 10;     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds = VAR == 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, EPI, VAR>;
     if (!attr_done) {
@@ -389,14 +479,15 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     e.flops_hint = 2.0 * (double)(e.rows_valid > 0 ? e.rows_valid : rows_alloc) * (double)(L.n_true ? L.n_true : L.N_pad) *
                    (double)(L.k_true ? L.k_true : L.K_pad);
     p.stagger = g_gemm_stagger;
-    p.W = L.W; p.K_pad = L.K_pad; p.bias = L.bias; p.colvec = L.colvec; p.N_pad = L.N_pad;
+    p.W = L.W; p.W3 = L.W3; p.K_pad = L.K_pad; p.bias = L.bias; p.colvec = L.colvec; p.N_pad = L.N_pad;
     p.e = e;
     if (epi_kind == EPI_LINEAR) {
         if (!e.C || e.ldc < L.N_pad) throw Error(FC_ERR_INVALID, "launch_gemm: output pitch smaller than N_pad");
         if (L.N_pad <= 64) { p.nbm = rows_alloc / 128; launch_cfg<128, 64, 4, 1, EPI_LINEAR>(p, s); }
         else if (L.N_pad % 128 == 0 || L.N_pad > 320) {
             p.nbm = rows_alloc / 128;
-            if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
+            if (g_gemm_variant == 3 && L.W3) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 3>(p, s);
+            else if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
             else if (g_gemm_variant == 1) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 1>(p, s);
             else launch_cfg<128, 128, 2, 2, EPI_LINEAR, 2>(p, s);
         }

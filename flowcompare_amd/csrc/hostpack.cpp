@@ -214,6 +214,40 @@ MatD inverse_double(const MatD& w) {
     return inv;
 }
 
+// ---------------------------------------------------------------- bf16 limbs
+static inline unsigned short f32_to_bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)((u >> 16) | ((u & 0xffffu) ? 0x40u : 0u));   // inf / nan
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float bf16_to_f32(unsigned short h) {
+    uint32_t u = (uint32_t)h << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+bool g_pack_bf16_limbs = true;
+
+std::vector<unsigned short> make_bf16_limbs(const std::vector<float>& w, int n_alloc, int K_pad) {
+    const int kt16 = K_pad / 16;
+    std::vector<unsigned short> w3((size_t)n_alloc * kt16 * 48, 0);
+    for (int n = 0; n < n_alloc; ++n)
+        for (int k = 0; k < K_pad; ++k) {
+            const float x = w[(size_t)n * K_pad + k];
+            if (x == 0.f) continue;
+            const unsigned short h = f32_to_bf16_rne(x);
+            const float r1 = x - bf16_to_f32(h);
+            const unsigned short m = f32_to_bf16_rne(r1);
+            const float r2 = r1 - bf16_to_f32(m);
+            const unsigned short l = f32_to_bf16_rne(r2);
+            unsigned short* dst = &w3[((size_t)n * kt16 + k / 16) * 48 + k % 16];
+            dst[0] = h; dst[16] = m; dst[32] = l;
+        }
+    return w3;
+}
+
 // ---------------------------------------------------------------- index maps
 std::vector<int> map_prefix(int n_src, int n_pad) {
     std::vector<int> m(n_pad, -1);
@@ -274,6 +308,15 @@ PackedLinear pack_linear(DeviceArena& arena, const MatD& W, const VecD& bias, co
     for (int k : kmap) L.k_true += k >= 0;
     L.W = arena.upload(w);
     L.bias = arena.upload(b);
+    if (g_pack_bf16_limbs && L.K_pad % 16 == 0) {
+        const std::vector<unsigned short> w3 = make_bf16_limbs(w, L.n_alloc, L.K_pad);
+        void* d = nullptr;
+        FC_HIP(hipMalloc(&d, w3.size() * sizeof(unsigned short)));
+        arena.blocks.push_back(d);
+        arena.total += w3.size() * sizeof(unsigned short);
+        FC_HIP(hipMemcpy(d, w3.data(), w3.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        L.W3 = (unsigned short*)d;
+    }
     L.colvec = colvec.empty() ? nullptr : arena.upload(cv);
     return L;
 }

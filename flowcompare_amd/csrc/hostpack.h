@@ -30,6 +30,9 @@ std::vector<int> map_xlayout(int d1, int d1_pad, int d2, int d2_pad);   // engin
 std::vector<int> map_pairs(int d2, int second_half_offset);        // [first 32 | second 32] x ceil(d2/32)
 std::vector<int> map_concat(const std::vector<std::vector<int>>& parts);
 
+// bf16 limb image of a packed fp32 weight matrix (host side): [n_alloc][K_pad/16][3][16], see PackedLinear.W3
+std::vector<unsigned short> make_bf16_limbs(const std::vector<float>& w, int n_alloc, int K_pad);
+
 // Build a PackedLinear: W_src [N_src x K_src], bias [N_src] (may be empty), colvec [N_src] (may be empty)
 PackedLinear pack_linear(DeviceArena& arena, const MatD& W, const VecD& bias, const VecD& colvec, const std::vector<int>& nmap,
                          const std::vector<int>& kmap, const std::vector<int>& seg_k);

@@ -58,6 +58,16 @@ int fc_op_linear_f32(const float* x, const float* W, const float* bias, const fl
     PackedLinear L;
     L.W = wp.f(); L.bias = bp.f(); L.N_pad = np; L.K_pad = kp; L.nseg = 1; L.seg_k[0] = kp; L.n_alloc = na;
     L.n_true = N; L.k_true = K;
+    std::unique_ptr<TmpBuf> w3buf;
+    if (g_gemm_variant == 3) {                                  // split-bf16 variant: limb image via a host round trip (test path only)
+        FC_HIP(hipStreamSynchronize(s));
+        std::vector<float> hw((size_t)na * kp);
+        FC_HIP(hipMemcpy(hw.data(), wp.f(), hw.size() * 4, hipMemcpyDeviceToHost));
+        const std::vector<unsigned short> w3 = make_bf16_limbs(hw, na, kp);
+        w3buf.reset(new TmpBuf(w3.size() * 2));
+        FC_HIP(hipMemcpy(w3buf->p, w3.data(), w3.size() * 2, hipMemcpyHostToDevice));
+        L.W3 = (unsigned short*)w3buf->p;
+    }
     GemmEpi e{};
     e.act = act; e.C = cp.f(); e.ldc = np;
     if (residual) { e.residual = rpad.f(); e.ldr = np; }

@@ -46,6 +46,31 @@ def test_linear_is_linear_and_exact_on_integers():
     assert torch.equal(y, x @ W.t())
 
 
+def test_split_bf16_variant_matches_fp64_like_fp32():
+    """The split-bf16 GEMM main loop (3 bf16 limbs, 6 MFMAs per product block) must be as accurate as the fp32 MFMA loop."""
+    lib = engine.lib()
+    try:
+        for rows, N, K, act in ((1000, 512, 512, "gelu"), (513, 3750, 512, "none"), (300, 256, 150, "none")):
+            x, W, b = _rand(rows, K, seed=1, scale=3.0), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3, scale=0.1)
+            ref = torch.nn.functional.linear(x.double(), W.double(), b.double())
+            if act == "gelu":
+                ref = torch.nn.functional.gelu(ref)
+            errs = {}
+            for var in (2, 3):
+                lib.fc_debug_set(0, var)
+                y = engine.op_linear(x.to(DEV), W.to(DEV), b.to(DEV), None, act).cpu().double()
+                errs[var] = (y - ref).abs().max().item()
+            print(f"split-bf16 {rows}x{N}x{K}: fp32-mfma err {errs[2]:.2e}  split-bf16 err {errs[3]:.2e}")
+            assert errs[3] < 2e-6 * max(1.0, K ** 0.5) and errs[3] < 4 * errs[2] + 1e-7
+        g = torch.Generator().manual_seed(5)
+        x = torch.randint(-8, 9, (384, 200), generator=g).float()
+        W = torch.randint(-8, 9, (512, 200), generator=g).float()
+        lib.fc_debug_set(0, 3)
+        assert torch.equal(engine.op_linear(x.to(DEV), W.to(DEV)).cpu(), x @ W.t())      # small integers: every limb product exact
+    finally:
+        lib.fc_debug_set(0, 3)            # shipped default
+
+
 @pytest.mark.parametrize("B,N,M,D", [(2, 128, 64, 64), (3, 100, 130, 64), (1, 20, 24, 32), (2, 257, 1000, 64), (1, 64, 4096, 64), (2, 40, 70, 128)])
 def test_attention_matches_fp64(B, N, M, D):
     q, k, v = _rand(B, N, D, seed=1, scale=2.0), _rand(B, M, D, seed=2, scale=2.0), _rand(B, M, D, seed=3)
