@@ -93,8 +93,8 @@ inline int gemm_bn(int N_pad, bool pair) {
     return 320;
 }
 inline int gemm_n_alloc(int N_pad) {
-    const int a = round_up(N_pad, gemm_bn(N_pad, false)), b = round_up(N_pad, 320);
-    return a > b ? a : b;
+    const int a = round_up(N_pad, gemm_bn(N_pad, false)), b = round_up(N_pad, 320), c = round_up(N_pad, 128);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 // A operand segment: rows x seg_k floats starting at ptr with row pitch lda
@@ -140,8 +140,8 @@ void launch_attention_op(const float* q, const float* k, const float* v, float* 
                          hipStream_t s);
 void launch_base_density(const float* x, int ldx, int d1, int d1_pad, int d2, float* logprob, float log_const,
                          float* z_out, int D, int rows, hipStream_t s);
-void launch_spline(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows,
-                   int inverse, hipStream_t s);
+void launch_spline(const float* params, int ldp, int d2s, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows,
+                   int inverse, hipStream_t s);   // params[row, p*d2s + j] = parameter p of dim j
 void launch_expm_coupling(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, const float* scal4, float* logprob,
                           int rows, int inverse, hipStream_t s);
 void launch_spline_flat(const float* x, const float* params, float* y, float* lad, int64_t n, int K, int inverse, hipStream_t s);

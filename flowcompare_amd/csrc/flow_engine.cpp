@@ -250,7 +250,12 @@ static void build_out_layer(fc_flow& f, const WeightTable& wt, const std::string
         const int per = 3 * f.cfg.num_bins_spline + 1;
         if (n != per * d.d1) throw Error(FC_ERR_SHAPE, prefix + ".out_layer: spline coupling expects (3K+1)*(D/2) outputs");
         if (n != per * d.d2) throw Error(FC_ERR_UNSUPPORTED, "spline coupling with odd latent_dim fails in the reference too (reshape)");
-        nmap = map_prefix(n, round_up(n, 32));
+        // parameter-major output: column p*d2s + j holds parameter p of transformed dim j (reference order is j*(3K+1) + p), so the
+        // spline kernel's lane j reads every parameter with a coalesced row access and needs no LDS transpose
+        const int d2s = round_up(d.d2, 8);
+        nmap.assign(round_up(per * d2s, 32), -1);
+        for (int pp = 0; pp < per; ++pp)
+            for (int j = 0; j < d.d2; ++j) nmap[pp * d2s + j] = j * per + pp;
     } else {
         if (n != d.d2 * d.d2 + d.d2) throw Error(FC_ERR_SHAPE, prefix + ".out_layer: exponential coupling expects d2^2 + d2 outputs");
         nmap = map_prefix(n, round_up(n, 32));
@@ -490,7 +495,7 @@ static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, c
         e.C = w.spl; e.ldc = d.ldp; e.rows_valid = w.P;
         launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_LINEAR, s);
         if (c.flow_type == FC_FLOW_SPLINE)
-            launch_spline(w.spl, d.ldp, xc, d.ldx, d.d1_pad, d.d2, c.num_bins_spline, logprob, w.P, inverse, s);
+            launch_spline(w.spl, d.ldp, round_up(d.d2, 8), xc, d.ldx, d.d1_pad, d.d2, c.num_bins_spline, logprob, w.P, inverse, s);
         else
             launch_expm_coupling(w.spl, d.ldp, xc, d.ldx, d.d1_pad, d.d2, b.expm_scal, logprob, w.P, inverse, s);
     }

@@ -90,10 +90,10 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmParams p) {
+    constexpr int NT = WM * WN * 64;                       // 4 or 8 waves per workgroup
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_F4 = BM * 8 / 256, B_F4 = BN * 8 / 256;
+    constexpr int A_F4 = BM * 8 / NT, B_F4 = BN * 8 / NT, RPP = NT / 8;   // float4 per thread and tile; rows per staging pass
     constexpr int STAGE = (BM + BN) * LDS_LD;
     extern __shared__ float smem[];
 
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
         // (PackedLinear.W3); activations are split while they are staged into LDS.  K tile = 16, LDS row = 3 limbs x 32 B + 16 B pad.
         constexpr int ROWB = 112;                                   // bytes per LDS row
         constexpr int STAGE3 = (BM + BN) * ROWB;
-        constexpr int A3 = BM / 64, W3N = BN * 6 / 256;            // float4 loads of A, 16-byte loads of W per thread and tile
+        constexpr int A3 = BM * 4 / NT, W3N = (BN * 6 + NT - 1) / NT, RPP3 = NT / 4;   // float4 loads of A, 16-byte loads of W per thread and tile
         char* smc = reinterpret_cast<char*>(smem);
         const int lrow3 = tid >> 2, lc3 = (tid & 3) * 4;
         const int KT16 = p.KT * 2;
@@ -211,9 +211,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
                 if (kk_ >= 2 * p.kt[1]) { kk_ -= 2 * p.kt[1]; Ap_ = p.A[2]; lda_ = p.lda[2]; }                     \
             }                                                                                                      \
             const float* a_ = Ap_ + (size_t)(m0 + lrow3) * lda_ + kk_ * 16 + lc3;                                  \
-            _Pragma("unroll") for (int i = 0; i < A3; ++i) ra3[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(64 * i) * lda_); \
+            _Pragma("unroll") for (int i = 0; i < A3; ++i) ra3[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(RPP3 * i) * lda_); \
             _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
-                const int c_ = tid + 256 * i, row_ = c_ / 6, part_ = c_ - row_ * 6;                                \
+                int c_ = tid + NT * i;                                                                             \
+                c_ = c_ < BN * 6 ? c_ : BN * 6 - 1;     /* unconditional load (a guarded one sends rw3 through scratch) */ \
+                const int row_ = c_ / 6, part_ = c_ - row_ * 6;                                                    \
                 rw3[i] = *reinterpret_cast<const uint4*>(p.W3 + ((size_t)(n0 + row_) * KT16 + (KT_)) * 48 + part_ * 8); \
             }                                                                                                      \
         }
@@ -229,13 +231,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
                     m_[e_] = (__bf16)r1_;                                                                          \
                     l_[e_] = (__bf16)(r1_ - (float)m_[e_]);                                                        \
                 }                                                                                                  \
-                *reinterpret_cast<bf16x4*>(sa_ + 64 * i * ROWB) = h_;                                               \
-                *reinterpret_cast<bf16x4*>(sa_ + 64 * i * ROWB + 32) = m_;                                          \
-                *reinterpret_cast<bf16x4*>(sa_ + 64 * i * ROWB + 64) = l_;                                          \
+                *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB) = h_;                                             \
+                *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB + 32) = m_;                                        \
+                *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB + 64) = l_;                                        \
             }                                                                                                      \
             _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
-                const int c_ = tid + 256 * i, row_ = c_ / 6, part_ = c_ - row_ * 6;                                \
-                *reinterpret_cast<uint4*>(smc + (ST_) * STAGE3 + (BM + row_) * ROWB + part_ * 16) = rw3[i];          \
+                const int c_ = tid + NT * i, row_ = c_ / 6, part_ = c_ - row_ * 6;                                 \
+                if (BN * 6 % NT == 0 || c_ < BN * 6)                                                               \
+                    *reinterpret_cast<uint4*>(smc + (ST_) * STAGE3 + (BM + row_) * ROWB + part_ * 16) = rw3[i];      \
             }                                                                                                      \
         }
         FC_GLOAD3(0)
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
     float4 ra[A_F4], rb[B_F4];
     const float* wbase = p.W + (size_t)(n0 + lrow) * p.K_pad + lc4;
-    const size_t wstep = (size_t)32 * p.K_pad;
+    const size_t wstep = (size_t)RPP * p.K_pad;
     float* const sAst = smem + lrow * LDS_LD + lc4;
     float* const sBst = sAst + BM * LDS_LD;
 
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
             if (kk_ >= p.kt[1]) { kk_ -= p.kt[1]; Ap_ = p.A[2]; lda_ = p.lda[2]; }                                 \
         }                                                                                                          \
         const float* a_ = Ap_ + (size_t)(m0 + lrow) * lda_ + kk_ * 32 + lc4;                                       \
-        _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(32 * i) * lda_); \
+        _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(RPP * i) * lda_); \
         const float* w_ = wbase + (KT_) * 32;                                                                      \
         _Pragma("unroll") for (int i = 0; i < B_F4; ++i) rb[i] = *reinterpret_cast<const float4*>(w_ + i * wstep);  \
     }
@@ -298,8 +301,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     {                                                                                                              \
         float* sa_ = sAst + (STAGE_) * STAGE;                                                                      \
         float* sb_ = sBst + (STAGE_) * STAGE;                                                                      \
-        _Pragma("unroll") for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(sa_ + 32 * i * LDS_LD) = ra[i]; \
-        _Pragma("unroll") for (int i = 0; i < B_F4; ++i) *reinterpret_cast<float4*>(sb_ + 32 * i * LDS_LD) = rb[i]; \
+        _Pragma("unroll") for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(sa_ + RPP * i * LDS_LD) = ra[i]; \
+        _Pragma("unroll") for (int i = 0; i < B_F4; ++i) *reinterpret_cast<float4*>(sb_ + RPP * i * LDS_LD) = rb[i]; \
     }
 
     FC_GLOAD(0)
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 3, g_gemm_stagger = 0, g_gemm_colgroup = 10;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 3, g_gemm_stagger = 0, g_gemm_colgroup = 10, g_gemm_bigtile = 0;     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
@@ -454,7 +457,7 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
     char name[96];
     snprintf(name, sizeof name, "void fc::gemm_f32_kernel<%d, %d, %d, %d, %d, %d>(fc::GemmParams)", BM, BN, WM, WN, EPI, VAR);
     ProfScope ps(name, p.e.flops_hint, 0.0, s);
-    hipLaunchKernelGGL(kern, dim3(q.nbm * q.nbn), dim3(256), lds, s, q);
+    hipLaunchKernelGGL(kern, dim3(q.nbm * q.nbn), dim3(WM * WN * 64), lds, s, q);
     FC_HIP(hipGetLastError());
 }
 
@@ -472,7 +475,7 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         kt += p.kt[i];
     }
     if (kt * 32 != L.K_pad) throw Error(FC_ERR_INVALID, "launch_gemm: segment widths do not add up to K_pad");
-    if (L.n_alloc < round_up(L.N_pad, gemm_bn(L.N_pad, epi_kind != EPI_LINEAR)))
+    if (L.n_alloc < round_up(L.N_pad, gemm_bn(L.N_pad, epi_kind != EPI_LINEAR)) || L.n_alloc < round_up(L.N_pad, 128))
         throw Error(FC_ERR_INVALID, "launch_gemm: W is not zero-padded to the column-tile grid (PackedLinear.n_alloc)");
     p.KT = kt;
     GemmEpi e = e_in;
@@ -481,23 +484,32 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     p.stagger = g_gemm_stagger;
     p.W = L.W; p.W3 = L.W3; p.K_pad = L.K_pad; p.bias = L.bias; p.colvec = L.colvec; p.N_pad = L.N_pad;
     p.e = e;
+    const bool split = g_gemm_variant == 3 && L.W3 != nullptr;
     if (epi_kind == EPI_LINEAR) {
         if (!e.C || e.ldc < L.N_pad) throw Error(FC_ERR_INVALID, "launch_gemm: output pitch smaller than N_pad");
-        if (L.N_pad <= 64) { p.nbm = rows_alloc / 128; launch_cfg<128, 64, 4, 1, EPI_LINEAR>(p, s); }
-        else if (L.N_pad % 128 == 0 || L.N_pad > 320) {
+        if (L.N_pad <= 64) {
             p.nbm = rows_alloc / 128;
-            if (g_gemm_variant == 3 && L.W3) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 3>(p, s);
-            else if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
-            else if (g_gemm_variant == 1) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 1>(p, s);
-            else launch_cfg<128, 128, 2, 2, EPI_LINEAR, 2>(p, s);
+            if (split) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 3>(p, s); else launch_cfg<128, 64, 4, 1, EPI_LINEAR>(p, s);
+        } else if (L.N_pad % 128 == 0 || L.N_pad > 320 || (split && L.n_alloc >= round_up(L.N_pad, 128))) {
+            // (with the split-bf16 loop two co-resident 128x128 workgroups beat the one-wave-per-SIMD 128x320 tile even at N = 320)
+            if (split && g_gemm_bigtile && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 3>(p, s); }
+            else {
+                p.nbm = rows_alloc / 128;
+                if (split) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 3>(p, s);
+                else if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
+                else if (g_gemm_variant == 1) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 1>(p, s);
+                else launch_cfg<128, 128, 2, 2, EPI_LINEAR, 2>(p, s);
+            }
+        } else {
+            p.nbm = rows_alloc / 128;
+            if (split) launch_cfg<128, 320, 4, 1, EPI_LINEAR, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_LINEAR>(p, s);
         }
-        else { p.nbm = rows_alloc / 128; launch_cfg<128, 320, 4, 1, EPI_LINEAR>(p, s); }
     } else {
         if (!L.bias || L.N_pad % 64 != 0) throw Error(FC_ERR_INVALID, "launch_gemm: pair-packed epilogue needs bias and N_pad % 64 == 0");
         p.nbm = rows_alloc / 128;
-        if (epi_kind == EPI_AFFINE) launch_cfg<128, 320, 4, 1, EPI_AFFINE>(p, s);
-        else if (epi_kind == EPI_AUGMENT) launch_cfg<128, 320, 4, 1, EPI_AUGMENT>(p, s);
-        else launch_cfg<128, 320, 4, 1, EPI_SLICE>(p, s);
+        if (epi_kind == EPI_AFFINE) { if (split) launch_cfg<128, 320, 4, 1, EPI_AFFINE, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_AFFINE>(p, s); }
+        else if (epi_kind == EPI_AUGMENT) { if (split) launch_cfg<128, 320, 4, 1, EPI_AUGMENT, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_AUGMENT>(p, s); }
+        else { if (split) launch_cfg<128, 320, 4, 1, EPI_SLICE, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_SLICE>(p, s); }
     }
 }
 

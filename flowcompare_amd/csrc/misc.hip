@@ -223,51 +223,34 @@ __device__ __forceinline__ void rq_any(int K, float x, const float* u, int us, b
     }
 }
 
-// One wave per point row: the row's (3K+1)*d2 parameters are staged in LDS with coalesced loads, then lane j
-// handles dims j, j+64, ... (LDS stride 3K+1 floats is odd -> conflict-free).  y2 overwrites x2 in place;
-// forward adds the row's sum of logabsdet to logprob.
-__global__ __launch_bounds__(256) void spline_rows_kernel(const float* __restrict__ params, int ldp, float* xbuf, int ldx, int x2_col0,
+// One wave per point row; lane j handles dims j, j+64, ...  The producing GEMM emits the parameters PARAMETER-major
+// (params[row, p*d2s + j]), so every parameter read is a coalesced row access (element stride d2s inside rq_spline_elem).
+// y2 overwrites x2 in place; forward adds the row's sum of logabsdet to logprob.
+__global__ __launch_bounds__(256) void spline_rows_kernel(const float* __restrict__ params, int ldp, int d2s, float* xbuf, int ldx, int x2_col0,
                                                           int d2, int K, float* logprob, int rows, int inverse) {
-    extern __shared__ float sp[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
-    const int npar = (3 * K + 1) * d2;
-    float* mine = sp + (size_t)wave * ((npar + 3) & ~3);
-    if (row < rows) {
-        const float* src = params + (size_t)row * ldp;
-        for (int c = lane * 4; c < npar; c += 256) {           // ldp and npar rounded so that float4 loads stay in the row
-            const float4 t = *reinterpret_cast<const float4*>(src + c);
-            *reinterpret_cast<float4*>(mine + c) = t;
-        }
-    }
-    __syncthreads();
     if (row >= rows) return;
+    const float* pr = params + (size_t)row * ldp;
     float acc = 0.f;
     float* xr = xbuf + (size_t)row * ldx + x2_col0;
     for (int j = lane; j < d2; j += 64) {
         float y, lad;
-        rq_any(K, xr[j], mine + j * (3 * K + 1), 1, inverse != 0, y, lad);
+        rq_any(K, xr[j], pr + j, d2s, inverse != 0, y, lad);
         xr[j] = y;
         acc += lad;
     }
     acc = wave_sum(acc);
     if (lane == 0 && !inverse) logprob[row] += acc;
 }
-void launch_spline(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows, int inverse,
+void launch_spline(const float* params, int ldp, int d2s, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows, int inverse,
                    hipStream_t s) {
     if (K != 4 && K != 8 && K != 16) throw Error(FC_ERR_UNSUPPORTED, "spline: num_bins_spline must be 4, 8 or 16");
-    const int npar = (3 * K + 1) * d2;
-    if (ldp < ((npar + 3) & ~3) || ldp % 4 != 0) throw Error(FC_ERR_INVALID, "spline: parameter pitch too small");
-    const size_t lds = 4 * (size_t)((npar + 3) & ~3) * sizeof(float);
-    if (lds > 160 * 1024) throw Error(FC_ERR_UNSUPPORTED, "spline: (3K+1)*d2 too large for the LDS-staged kernel");
-    static bool attr_done = false;
-    if (!attr_done) {
-        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spline_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
-    ProfScope ps("fc::spline_rows_kernel(float const*, int, float*, int, int, int, int, float*, int, int)", 0.0,
-                 4.0 * rows * ((double)npar + 2.0 * d2 + 2.0), s);
-    hipLaunchKernelGGL(spline_rows_kernel, dim3((rows + 3) / 4), dim3(256), lds, s, params, ldp, xbuf, ldx, x2_col0, d2, K, logprob, rows, inverse);
+    const int npar = (3 * K + 1) * d2s;
+    if (ldp < npar || d2s < d2) throw Error(FC_ERR_INVALID, "spline: parameter pitch too small");
+    ProfScope ps("fc::spline_rows_kernel(float const*, int, int, float*, int, int, int, int, float*, int, int)", 0.0,
+                 4.0 * rows * ((3.0 * K + 1) * d2 + 2.0 * d2 + 2.0), s);
+    hipLaunchKernelGGL(spline_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, params, ldp, d2s, xbuf, ldx, x2_col0, d2, K, logprob, rows, inverse);
     FC_HIP(hipGetLastError());
 }
 

@@ -23,7 +23,7 @@ struct TmpBuf {
     catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; } \
     return FC_OK;
 
-namespace fc { extern int g_gemm_variant, g_gemm_stagger, g_gemm_colgroup; }
+namespace fc { extern int g_gemm_variant, g_gemm_stagger, g_gemm_colgroup, g_gemm_bigtile; }
 
 extern "C" {
 
@@ -32,6 +32,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     if (key == 0) fc::g_gemm_variant = value;
     else if (key == 1) fc::g_gemm_stagger = value;
     else if (key == 2) fc::g_gemm_colgroup = value;
+    else if (key == 3) fc::g_gemm_bigtile = value;
     else return FC_ERR_INVALID;
     return FC_OK;
 }
