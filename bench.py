@@ -33,7 +33,8 @@ ALG_MFLOP_PER_POINT = {"c1_dgcnn_global_affine": 396.0, "c2_dgcnn_attn_spline": 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MATRIX_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse headline)
 PEAK_HBM_GBS = 8000.0
-SPLIT_BF16_MFMA_PER_PRODUCT = 6     # the split-bf16 GEMM loop issues 6 bf16 MFMAs per fp32-equivalent product block (gemm.hip)
+SPLIT_MFMA_PER_PRODUCT = {5: 3, 3: 6}   # gemm.hip: the split-fp16 loop (VAR 5) issues 3 fp16 MFMAs per fp32-equivalent product block, the
+                                        # split-bf16 loop (VAR 3, its fallback) 6 bf16 MFMAs; both run at the 2500 TFLOP/s dense 16-bit rate
 
 
 def synth_pairs(B, n_ctx, n_tgt, seed, device):
@@ -96,8 +97,14 @@ def main():
     ap.add_argument("--points", type=int, default=4096, help="target points = context points per scene")
     ap.add_argument("--layers", type=int, default=None, help="override n_flow_layers (INVALID as a headline number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--knob", action="append", default=[], help="K=V tuning knob for same-box A/B runs (fc_debug_set); not for headline numbers")
     ap.add_argument("--cpu-points", type=int, default=None, help="points per scene of the CPU sample (default: same as --points)")
     args = ap.parse_args()
+    for kv in args.knob:
+        k, v = kv.split("=")
+        from flowcompare_amd import engine as _eng
+        if _eng.lib().fc_debug_set(int(k), int(v)) != 0:
+            raise SystemExit(f"unknown --knob {kv}")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -169,12 +176,14 @@ def main():
         per_launch_ms = dom["ms"] / dom["launches"]
         if dom["flops"] > 0:
             useful = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12          # fp32-equivalent multiply-add TFLOP/s
-            split = dom["kernel"].rstrip(")").endswith("3>(fc::GemmParams")                  # ..., VAR = 3>: split-bf16 main loop
-            if split:
-                achieved, peak = useful * SPLIT_BF16_MFMA_PER_PRODUCT, PEAK_BF16_MATRIX_TFLOPS
-                note = ("split-bf16 loop: achieved = bf16 MFMA FLOPs actually issued (6 limb products per fp32-equivalent product, padding "
-                        "excluded) against the dense bf16 MFMA peak 2500 TFLOP/s; useful_fp32_equivalent_tflops is the same launch time "
-                        "priced in fp32-equivalent FLOPs (the fp32-input MFMA peak is 157.3 TFLOP/s)")
+            var = next((v for v in SPLIT_MFMA_PER_PRODUCT if dom["kernel"].endswith(f", {v}>(fc::GemmParams)")), None)   # ..., VAR>
+            if var is not None:
+                n = SPLIT_MFMA_PER_PRODUCT[var]
+                achieved, peak = useful * n, PEAK_BF16_MATRIX_TFLOPS
+                note = (f"split-{'fp16' if var == 5 else 'bf16'} loop: achieved = 16-bit MFMA FLOPs actually issued ({n} limb products per "
+                        "fp32-equivalent product, padding excluded) against the dense fp16/bf16 MFMA peak 2500 TFLOP/s; "
+                        "useful_fp32_equivalent_tflops is the same launch time priced in fp32-equivalent FLOPs (the fp32-input MFMA "
+                        "peak is 157.3 TFLOP/s)")
             else:
                 achieved, peak = useful, PEAK_F32_MATRIX_TFLOPS
                 note = "fp32-input MFMA (v_mfma_f32_32x32x2_f32) against its dense peak 157.3 TFLOP/s"
@@ -190,7 +199,7 @@ def main():
         out = {
             "metric": "nats/sec (forward log-prob) on 4096-pt coloured pairs", "value": value, "unit": "nats/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3 (fp32-equivalent split, f32 accumulate) / f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16x2 split (fp32-equivalent operands, f32 accumulate) / f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: batch {B} scenes/GPU x {N} target + {N} context points, "
                                    f"{cfg['n_flow_layers']} flow layers ({cfg['flow_type']}), embedder {cfg['input_embedder']}",
                        "global_batch": world * B, "points_per_scene": N, "parallelism": f"scene-sharded x{world}, no data-path collective"},

@@ -74,6 +74,8 @@ struct PackedLinear {
     float* W = nullptr;        // [N_alloc][K_pad] row-major, zero padded
     float* bias = nullptr;     // [N_alloc]
     float* colvec = nullptr;   // [N_alloc] or null: rank-1 term  C += rowscal[row] * colvec[n]
+    unsigned short* W2 = nullptr;  // the same matrix as 2 fp16 limbs, [N_alloc][K_pad/16][2][16]: w ~= hi + lo'/2048 to 2^-24 (null when an entry
+                                   // does not fit fp16): operand of the default split-fp16 GEMM loop
     unsigned short* W3 = nullptr;  // the same matrix as 3 bf16 limbs, [N_alloc][K_pad/16][3][16]: x = hi + mid + lo exactly to 24 bits
                                    // (operand image of the split-bf16 GEMM variant, see gemm.hip)
     int N_pad = 0;             // columns written (multiple of 32)
@@ -126,6 +128,24 @@ struct GemmEpi {
     double flops_hint = 0.0;   // filled by launch_gemm for the profiler
 };
 
+// The split-fp16 GEMM loop (the default) cannot represent |activation| >= 65504.  It therefore only runs inside a guard scope of
+// the calling thread: the scope hands the kernels a device flag they raise on such a value, and the entry point that opened the
+// scope repeats its whole computation with the bf16-limb loop (unbounded range) when the flag came back set.  Outside a scope
+// launch_gemm always takes the bf16-limb loop.
+struct Fp16Guard {
+    Fp16Guard(int* dev_flag, hipStream_t s);
+    ~Fp16Guard();
+    bool overflowed();            // closes the scope: waits for the stream and reads the flag
+    int* flag; hipStream_t stream; bool open;
+};
+bool gemm_fp16_enabled();
+template <class F>
+inline void run_fp16_guarded(int* dev_flag, hipStream_t s, F&& fn) {
+    if (!dev_flag || !gemm_fp16_enabled()) { fn(); return; }
+    bool over;
+    { Fp16Guard g(dev_flag, s); fn(); over = g.overflowed(); }
+    if (over) fn();
+}
 void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const GemmEpi& e, int epi_kind, hipStream_t s);
 
 // ---------------------------------------------------------------- other kernels (misc.hip / attention.hip / knn.hip)

@@ -15,6 +15,7 @@
 #include "hostpack.h"
 
 struct fc_dgcnn {
+    int* fp16_flag = nullptr;   // device word raised by the split-fp16 GEMM loop on an activation >= 65504 (common.h: Fp16Guard)
     fc::DeviceArena arena;
     int k = 0, global_pool = 0, c_in = 0, E = 0, E_pad = 0, H_pad = 0;
     fc::PackedLinear level[4];
@@ -188,7 +189,11 @@ int fc_dgcnn_workspace_bytes(const fc_dgcnn* emb, int32_t B, int32_t M, size_t* 
 int fc_dgcnn_embed_f32(fc_dgcnn* emb, const float* pts, float* out, int32_t B, int32_t M, void* workspace, size_t workspace_bytes, void* stream) {
     FC_API_BEGIN
     if (!emb || !workspace) throw fc::Error(FC_ERR_INVALID, "fc_dgcnn_embed_f32: null handle / workspace");
-    fc::dgcnn_forward(*emb, pts, out, B, M, workspace, workspace_bytes, (hipStream_t)stream);
+    if (!emb->fp16_flag) emb->fp16_flag = (int*)emb->arena.alloc_floats(1);
+    // fast split-fp16 GEMMs first; the whole pass is repeated with the bf16-limb GEMMs if an activation left fp16's range
+    fc::run_fp16_guarded(emb->fp16_flag, (hipStream_t)stream, [&] {
+        fc::dgcnn_forward(*emb, pts, out, B, M, workspace, workspace_bytes, (hipStream_t)stream);
+    });
     FC_API_END
 }
 

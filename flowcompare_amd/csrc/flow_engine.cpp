@@ -64,6 +64,7 @@ struct Dims {
 }  // namespace fc
 
 struct fc_flow {
+    int* fp16_flag = nullptr;   // device word raised by the split-fp16 GEMM loop on an activation >= 65504 (common.h: Fp16Guard)
     fc_flow_config cfg;
     fc::Dims d;
     fc::DeviceArena arena;
@@ -715,7 +716,11 @@ int fc_flow_logprob_f32(fc_flow* flow, const float* x, const float* ctx, const f
                         float* logprob, float* z_out, int32_t B, int32_t N, int32_t M, void* workspace, size_t workspace_bytes, void* stream) {
     FC_API_BEGIN
     if (!flow || !workspace) throw fc::Error(FC_ERR_INVALID, "fc_flow_logprob_f32: null flow / workspace");
-    fc::flow_forward(*flow, x, ctx, extra, eps, n_eps, logprob, z_out, B, N, M, workspace, workspace_bytes, (hipStream_t)stream);
+    if (!flow->fp16_flag) flow->fp16_flag = (int*)flow->arena.alloc_floats(1);
+    // fast split-fp16 GEMMs first; the whole pass is repeated with the bf16-limb GEMMs if an activation left fp16's range
+    fc::run_fp16_guarded(flow->fp16_flag, (hipStream_t)stream, [&] {
+        fc::flow_forward(*flow, x, ctx, extra, eps, n_eps, logprob, z_out, B, N, M, workspace, workspace_bytes, (hipStream_t)stream);
+    });
     FC_API_END
 }
 

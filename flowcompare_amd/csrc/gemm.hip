@@ -14,6 +14,7 @@
 // Global -> LDS goes through registers (prefetch of tile t+1 is issued before the MFMAs of tile t, written
 // after them): one barrier per 32-deep K tile.
 #include "common.h"
+#include <atomic>
 #include <cstdio>
 
 namespace fc {
@@ -21,6 +22,8 @@ namespace fc {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 struct GemmParams {
     const float* A[3];
@@ -29,6 +32,8 @@ struct GemmParams {
     int KT;             // total k tiles
     const float* W;     // [N_pad][K_pad]
     const unsigned short* W3;   // bf16 limb image [n_alloc][K_pad/16][3][16] (split-bf16 variant)
+    const unsigned short* W2;   // fp16 limb image [n_alloc][K_pad/16][2][16]: hi, lo' = (w - hi) * 2048 (split-fp16 variant)
+    int* ovf;                   // split-fp16 variant: set to 1 when an activation >= 65504 was met
     int K_pad;
     const float* bias;
     const float* colvec;
@@ -90,7 +95,8 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN <= 128 ? 2 : 1)))   // two resident workgroups per CU for the <= 128-wide tiles
+void gemm_f32_kernel(const GemmParams p) {
     constexpr int NT = WM * WN * 64;                       // 4 or 8 waves per workgroup
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_F4 = BM * 8 / NT, B_F4 = BN * 8 / NT, RPP = NT / 8;   // float4 per thread and tile; rows per staging pass
@@ -187,22 +193,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmParams
         }
     }
 
-    if constexpr (VAR == 3) {
+    if constexpr (VAR >= 3) {
         // ================= split-bf16 main loop: fp32-equivalent products on the bf16 matrix cores =================
         // x = hi + mid + lo (three bf16 limbs, 24 significant bits);  a*b ~= ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh),
         // the dropped terms are below 2^-24 |a b|.  Every limb product is exact in the MFMA's fp32 accumulator, so the result
         // has fp32-GEMM accuracy (profiles/micro: 6e-9 rel. error with exact accumulation) at 6 bf16 MFMAs (32 cycles each)
         // per 32x32x16 block instead of 8 fp32 MFMAs (64 cycles each): 2.67x the matrix rate.  Weights are pre-split on the host
         // (PackedLinear.W3); activations are split while they are staged into LDS.  K tile = 16, LDS row = 3 limbs x 32 B + 16 B pad.
-        constexpr int ROWB = 112;                                   // bytes per LDS row
+        //
+        // VAR 5, the default: TWO fp16 limbs.  x = hi + lo'/2048 with hi = rn16(x), lo' = rn16((x - hi) * 2048): hi carries 11 bits,
+        // the scaled remainder the next 11 (+ sign), so the pair represents x to 2^-24 relative -- fp32's own rounding unit -- and
+        // the scaling keeps lo' out of fp16's subnormal range (abs. error floor 2^-36 per element).  a*b ~= ah*bh + (ah*bl' +
+        // al'*bh)/2048: the h*h products go to the main accumulator, the two cross products to a second one that is scaled by
+        // 2^-11 (exact) and added once after the k loop; the dropped l*l term is < 2^-24 |a b|.  3 MFMAs per block instead of 6
+        // (5.3x the fp32-input matrix rate), 4 bytes per LDS element instead of 6.  fp16 overflows at 65504: every staged |x| is
+        // max-reduced and a launch that met one >= 65504 raises *p.ovf; the entry point then repeats the whole call with the
+        // bf16 limbs (unbounded range).  Weights with such entries never get an fp16 image (PackedLinear.W2 == nullptr).
+        constexpr bool F16 = VAR == 5;
+        constexpr int NL = F16 ? 2 : 3;                             // limbs
+        constexpr int ROWB = NL * 32 + 16;                          // bytes per LDS row (16 B pad: conflict-free 16-byte fragment reads)
+        constexpr int CH = NL * 2;                                  // 16-byte chunks per (row, k tile) of a limb image
         constexpr int STAGE3 = (BM + BN) * ROWB;
-        constexpr int A3 = BM * 4 / NT, W3N = (BN * 6 + NT - 1) / NT, RPP3 = NT / 4;   // float4 loads of A, 16-byte loads of W per thread and tile
+        constexpr int A3 = BM * 4 / NT, W3N = (BN * CH + NT - 1) / NT, RPP3 = NT / 4;   // float4 loads of A, 16-byte loads of W per thread and tile
         char* smc = reinterpret_cast<char*>(smem);
         const int lrow3 = tid >> 2, lc3 = (tid & 3) * 4;
         const int KT16 = p.KT * 2;
-        float4 ra3[A3];
-        uint4 rw3[W3N];
-#define FC_GLOAD3(KT_)                                                                                             \
+        const unsigned short* const Wl = F16 ? p.W2 : p.W3;
+        float amax = 0.f;
+        // two register sets: the tile loaded in iteration kt is only converted/stored in iteration kt+1, so a global load has a
+        // whole iteration (the MFMAs of the other resident waves included) to land before anything waits for it
+        float4 ra3_0[A3], ra3_1[A3];
+        typedef unsigned int u32xw __attribute__((ext_vector_type(4 * W3N)));      // whole-vector values: never an alloca, so never scratch
+        u32xw rw3_0, rw3_1;
+#define FC_GLOAD3(S_, KT_)                                                                                           \
         {                                                                                                          \
             const float* Ap_ = p.A[0];                                                                             \
             int lda_ = p.lda[0], kk_ = (KT_);                                                                      \
@@ -211,67 +234,117 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmParams
                 if (kk_ >= 2 * p.kt[1]) { kk_ -= 2 * p.kt[1]; Ap_ = p.A[2]; lda_ = p.lda[2]; }                     \
             }                                                                                                      \
             const float* a_ = Ap_ + (size_t)(m0 + lrow3) * lda_ + kk_ * 16 + lc3;                                  \
-            _Pragma("unroll") for (int i = 0; i < A3; ++i) ra3[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(RPP3 * i) * lda_); \
+            _Pragma("unroll") for (int i = 0; i < A3; ++i) ra3_##S_[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(RPP3 * i) * lda_); \
             _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
                 int c_ = tid + NT * i;                                                                             \
-                c_ = c_ < BN * 6 ? c_ : BN * 6 - 1;     /* unconditional load (a guarded one sends rw3 through scratch) */ \
-                const int row_ = c_ / 6, part_ = c_ - row_ * 6;                                                    \
-                rw3[i] = *reinterpret_cast<const uint4*>(p.W3 + ((size_t)(n0 + row_) * KT16 + (KT_)) * 48 + part_ * 8); \
+                c_ = c_ < BN * CH ? c_ : BN * CH - 1;     /* unconditional load (a guarded one sends the staging registers through scratch) */ \
+                const int row_ = c_ / CH, part_ = c_ - row_ * CH;                                                  \
+                const uint4 t_ = *reinterpret_cast<const uint4*>(Wl + ((size_t)(n0 + row_) * KT16 + (KT_)) * (NL * 16) + part_ * 8); \
+                rw3_##S_[4 * i] = t_.x; rw3_##S_[4 * i + 1] = t_.y; rw3_##S_[4 * i + 2] = t_.z; rw3_##S_[4 * i + 3] = t_.w; \
             }                                                                                                      \
         }
-#define FC_LSTORE3(ST_)                                                                                            \
+#define FC_LSTORE3(S_, ST_)                                                                                          \
         {                                                                                                          \
             char* sa_ = smc + (ST_) * STAGE3 + lrow3 * ROWB + (tid & 3) * 8;                                        \
             _Pragma("unroll") for (int i = 0; i < A3; ++i) {                                                       \
-                const float x_[4] = {ra3[i].x, ra3[i].y, ra3[i].z, ra3[i].w};                                      \
-                bf16x4 h_, m_, l_;                                                                                 \
-                _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                 \
-                    h_[e_] = (__bf16)x_[e_];                                                                       \
-                    const float r1_ = x_[e_] - (float)h_[e_];                                                      \
-                    m_[e_] = (__bf16)r1_;                                                                          \
-                    l_[e_] = (__bf16)(r1_ - (float)m_[e_]);                                                        \
+                const float x_[4] = {ra3_##S_[i].x, ra3_##S_[i].y, ra3_##S_[i].z, ra3_##S_[i].w};                  \
+                if constexpr (F16) {                                                                               \
+                    f16x4 h_, l_;                                                                                  \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                             \
+                        amax = fmaxf(amax, fabsf(x_[e_]));                                                         \
+                        h_[e_] = (_Float16)x_[e_];                                                                 \
+                        l_[e_] = (_Float16)((x_[e_] - (float)h_[e_]) * 2048.0f);                                   \
+                    }                                                                                              \
+                    *reinterpret_cast<f16x4*>(sa_ + RPP3 * i * ROWB) = h_;                                          \
+                    *reinterpret_cast<f16x4*>(sa_ + RPP3 * i * ROWB + 32) = l_;                                     \
+                } else {                                                                                           \
+                    bf16x4 h_, m_, l_;                                                                             \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                             \
+                        h_[e_] = (__bf16)x_[e_];                                                                   \
+                        const float r1_ = x_[e_] - (float)h_[e_];                                                  \
+                        m_[e_] = (__bf16)r1_;                                                                      \
+                        l_[e_] = (__bf16)(r1_ - (float)m_[e_]);                                                    \
+                    }                                                                                              \
+                    *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB) = h_;                                         \
+                    *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB + 32) = m_;                                    \
+                    *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB + 64) = l_;                                    \
                 }                                                                                                  \
-                *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB) = h_;                                             \
-                *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB + 32) = m_;                                        \
-                *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB + 64) = l_;                                        \
             }                                                                                                      \
             _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
-                const int c_ = tid + NT * i, row_ = c_ / 6, part_ = c_ - row_ * 6;                                 \
-                if (BN * 6 % NT == 0 || c_ < BN * 6)                                                               \
-                    *reinterpret_cast<uint4*>(smc + (ST_) * STAGE3 + (BM + row_) * ROWB + part_ * 16) = rw3[i];      \
+                const int c_ = tid + NT * i, row_ = c_ / CH, part_ = c_ - row_ * CH;                               \
+                if (BN * CH % NT == 0 || c_ < BN * CH)                                                             \
+                    *reinterpret_cast<uint4*>(smc + (ST_) * STAGE3 + (BM + row_) * ROWB + part_ * 16) =                    \
+                        make_uint4(rw3_##S_[4 * i], rw3_##S_[4 * i + 1], rw3_##S_[4 * i + 2], rw3_##S_[4 * i + 3]);   \
             }                                                                                                      \
         }
-        FC_GLOAD3(0)
-        FC_LSTORE3(0)
-        __syncthreads();
-        for (int kt = 0; kt < KT16; ++kt) {
-            const int ktn = kt + 1 < KT16 ? kt + 1 : kt;
-            FC_GLOAD3(ktn)
-            const char* sA = smc + (kt & 1) * STAGE3 + (wr * TM * 32 + li) * ROWB + lh * 16;
-            const char* sB = smc + (kt & 1) * STAGE3 + (BM + wc * TN * 32 + li) * ROWB + lh * 16;
-            bf16x8 af3[TM][3], bf3[TN][3];
+#define FC_MMA3(ST_)                                                                                              \
+        {                                                                                                          \
+            const char* sA = smc + (ST_) * STAGE3 + (wr * TM * 32 + li) * ROWB + lh * 16;                           \
+            const char* sB = smc + (ST_) * STAGE3 + (BM + wc * TN * 32 + li) * ROWB + lh * 16;                      \
+            if constexpr (F16) {                                                                                   \
+                f16x8 af3[TM][2], bf3[TN][2];                                                                      \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
+                    _Pragma("unroll") for (int q = 0; q < 2; ++q) af3[i][q] = *reinterpret_cast<const f16x8*>(sA + i * 32 * ROWB + q * 32); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
+                    _Pragma("unroll") for (int q = 0; q < 2; ++q) bf3[j][q] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + q * 32); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
+                    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af3[i][0], bf3[j][0], acc[i][j], 0, 0, 0);     /* hi * hi */  \
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af3[i][0], bf3[j][1], corr[i][j], 0, 0, 0);   /* hi * lo' */ \
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af3[i][1], bf3[j][0], corr[i][j], 0, 0, 0);   /* lo' * hi */ \
+                    }                                                                                              \
+            } else {                                                                                               \
+                bf16x8 af3[TM][3], bf3[TN][3];                                                                     \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
+                    _Pragma("unroll") for (int q = 0; q < 3; ++q) af3[i][q] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * ROWB + q * 32); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
+                    _Pragma("unroll") for (int q = 0; q < 3; ++q) bf3[j][q] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * ROWB + q * 32); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
+                    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][2], bf3[j][0], acc[i][j], 0, 0, 0);   /* lo * hi */   \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][1], bf3[j][1], acc[i][j], 0, 0, 0);   /* mid * mid */ \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][0], bf3[j][2], acc[i][j], 0, 0, 0);   /* hi * lo */   \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][1], bf3[j][0], acc[i][j], 0, 0, 0);   /* mid * hi */  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][0], bf3[j][1], acc[i][j], 0, 0, 0);   /* hi * mid */  \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][0], bf3[j][0], acc[i][j], 0, 0, 0);   /* hi * hi */   \
+                    }                                                                                              \
+            }                                                                                                      \
+        }
+        floatx16 corr[F16 ? TM : 1][F16 ? TN : 1];
+        if constexpr (F16) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) af3[i][q] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * ROWB + q * 32);
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) bf3[j][q] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * ROWB + q * 32);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][2], bf3[j][0], acc[i][j], 0, 0, 0);   // lo * hi
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][1], bf3[j][1], acc[i][j], 0, 0, 0);   // mid * mid
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][0], bf3[j][2], acc[i][j], 0, 0, 0);   // hi * lo
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][1], bf3[j][0], acc[i][j], 0, 0, 0);   // mid * hi
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][0], bf3[j][1], acc[i][j], 0, 0, 0);   // hi * mid
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][0], bf3[j][0], acc[i][j], 0, 0, 0);   // hi * hi
-                }
-            FC_LSTORE3((kt + 1) & 1)
+                    for (int r = 0; r < 16; ++r) corr[i][j][r] = 0.f;
+        }
+        // KT16 is even (K_pad is a multiple of 32).  Stage s of LDS holds tile kt (s = kt & 1); register set s holds tile kt+1 ... kt+2.
+        FC_GLOAD3(0, 0)
+        FC_LSTORE3(0, 0)
+        FC_GLOAD3(1, 1)
+        __syncthreads();
+        for (int kt = 0; kt < KT16; kt += 2) {
+            const int k2 = kt + 2 < KT16 ? kt + 2 : KT16 - 1, k3 = kt + 3 < KT16 ? kt + 3 : KT16 - 1;   // tail re-loads: branch-free loop
+            FC_GLOAD3(0, k2)
+            FC_MMA3(0)
+            FC_LSTORE3(1, 1)
+            __syncthreads();
+            FC_GLOAD3(1, k3)
+            FC_MMA3(1)
+            FC_LSTORE3(0, 0)
             __syncthreads();
         }
+        if constexpr (F16) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += corr[i][j][r] * (1.0f / 2048.0f);
+            if (amax >= 65504.0f) atomicOr(p.ovf, 1);               // some |x| does not fit fp16: the caller repeats with bf16 limbs
+        }
+#undef FC_MMA3
 #undef FC_GLOAD3
 #undef FC_LSTORE3
     } else {
@@ -438,11 +511,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_f32_kernel(const GemmParams
     }
 }
 
-int g_gemm_variant = 3, g_gemm_stagger = 0, g_gemm_colgroup = 10, g_gemm_bigtile = 0;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 5, g_gemm_stagger = 0, g_gemm_colgroup = 10, g_gemm_bigtile = 0;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+
+static thread_local int* t_fp16_flag = nullptr;
+static std::atomic<long> g_fp16_fallbacks{0};
+
+bool gemm_fp16_enabled() { return g_gemm_variant == 5; }
+long gemm_fp16_fallbacks() { return g_fp16_fallbacks.load(); }
+Fp16Guard::Fp16Guard(int* dev_flag, hipStream_t s) : flag(dev_flag), stream(s), open(true) {
+    FC_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+    t_fp16_flag = flag;
+}
+Fp16Guard::~Fp16Guard() { t_fp16_flag = nullptr; }
+bool Fp16Guard::overflowed() {
+    t_fp16_flag = nullptr;
+    open = false;
+    int h = 0;
+    FC_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    FC_HIP(hipStreamSynchronize(stream));
+    if (h) g_fp16_fallbacks.fetch_add(1);
+    return h != 0;
+}
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds = VAR == 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds = VAR == 5 ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, EPI, VAR>;
     if (!attr_done) {
@@ -482,20 +575,24 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     e.flops_hint = 2.0 * (double)(e.rows_valid > 0 ? e.rows_valid : rows_alloc) * (double)(L.n_true ? L.n_true : L.N_pad) *
                    (double)(L.k_true ? L.k_true : L.K_pad);
     p.stagger = g_gemm_stagger;
-    p.W = L.W; p.W3 = L.W3; p.K_pad = L.K_pad; p.bias = L.bias; p.colvec = L.colvec; p.N_pad = L.N_pad;
+    p.W = L.W; p.W3 = L.W3; p.W2 = L.W2; p.ovf = t_fp16_flag; p.K_pad = L.K_pad; p.bias = L.bias; p.colvec = L.colvec; p.N_pad = L.N_pad;
     p.e = e;
-    const bool split = g_gemm_variant == 3 && L.W3 != nullptr;
+    const bool split = (g_gemm_variant == 3 || g_gemm_variant == 5) && L.W3 != nullptr;
+    const bool f16 = g_gemm_variant == 5 && L.W2 != nullptr && t_fp16_flag != nullptr;
     if (epi_kind == EPI_LINEAR) {
         if (!e.C || e.ldc < L.N_pad) throw Error(FC_ERR_INVALID, "launch_gemm: output pitch smaller than N_pad");
         if (L.N_pad <= 64) {
             p.nbm = rows_alloc / 128;
-            if (split) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 3>(p, s); else launch_cfg<128, 64, 4, 1, EPI_LINEAR>(p, s);
+            if (f16) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 5>(p, s);
+            else if (split) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 3>(p, s);
+            else launch_cfg<128, 64, 4, 1, EPI_LINEAR>(p, s);
         } else if (L.N_pad % 128 == 0 || L.N_pad > 320 || (split && L.n_alloc >= round_up(L.N_pad, 128))) {
             // (with the split-bf16 loop two co-resident 128x128 workgroups beat the one-wave-per-SIMD 128x320 tile even at N = 320)
             if (split && g_gemm_bigtile && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 3>(p, s); }
             else {
                 p.nbm = rows_alloc / 128;
-                if (split) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 3>(p, s);
+                if (f16) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 5>(p, s);
+                else if (split) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 3>(p, s);
                 else if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
                 else if (g_gemm_variant == 1) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 1>(p, s);
                 else launch_cfg<128, 128, 2, 2, EPI_LINEAR, 2>(p, s);

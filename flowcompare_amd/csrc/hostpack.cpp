@@ -248,6 +248,26 @@ std::vector<unsigned short> make_bf16_limbs(const std::vector<float>& w, int n_a
     return w3;
 }
 
+// fp16 limb image for the split-fp16 GEMM loop: [n_alloc][K_pad/16][2][16] = hi, lo' with w ~= hi + lo'/2048 (gemm.hip).
+// Returns an empty vector when an entry does not fit fp16 (|w| >= 65504 or not finite): that layer keeps the bf16 limbs only.
+std::vector<unsigned short> make_f16_limbs(const std::vector<float>& w, int n_alloc, int K_pad) {
+    const int kt16 = K_pad / 16;
+    std::vector<unsigned short> w2((size_t)n_alloc * kt16 * 32, 0);
+    for (int n = 0; n < n_alloc; ++n)
+        for (int k = 0; k < K_pad; ++k) {
+            const float x = w[(size_t)n * K_pad + k];
+            if (x == 0.f) continue;
+            if (!(std::fabs(x) < 65504.0f)) return {};
+            const _Float16 h = (_Float16)x;                                   // round to nearest even
+            const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+            unsigned short hb, lb;
+            std::memcpy(&hb, &h, 2); std::memcpy(&lb, &l, 2);
+            unsigned short* dst = &w2[((size_t)n * kt16 + k / 16) * 32 + k % 16];
+            dst[0] = hb; dst[16] = lb;
+        }
+    return w2;
+}
+
 // ---------------------------------------------------------------- index maps
 std::vector<int> map_prefix(int n_src, int n_pad) {
     std::vector<int> m(n_pad, -1);
@@ -316,6 +336,15 @@ PackedLinear pack_linear(DeviceArena& arena, const MatD& W, const VecD& bias, co
         arena.total += w3.size() * sizeof(unsigned short);
         FC_HIP(hipMemcpy(d, w3.data(), w3.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         L.W3 = (unsigned short*)d;
+        const std::vector<unsigned short> w2 = make_f16_limbs(w, L.n_alloc, L.K_pad);
+        if (!w2.empty()) {
+            void* d2 = nullptr;
+            FC_HIP(hipMalloc(&d2, w2.size() * sizeof(unsigned short)));
+            arena.blocks.push_back(d2);
+            arena.total += w2.size() * sizeof(unsigned short);
+            FC_HIP(hipMemcpy(d2, w2.data(), w2.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            L.W2 = (unsigned short*)d2;
+        }
     }
     L.colvec = colvec.empty() ? nullptr : arena.upload(cv);
     return L;

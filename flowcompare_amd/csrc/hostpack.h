@@ -31,6 +31,7 @@ std::vector<int> map_pairs(int d2, int second_half_offset);        // [first 32 
 std::vector<int> map_concat(const std::vector<std::vector<int>>& parts);
 
 // bf16 limb image of a packed fp32 weight matrix (host side): [n_alloc][K_pad/16][3][16], see PackedLinear.W3
+std::vector<unsigned short> make_f16_limbs(const std::vector<float>& w, int n_alloc, int K_pad);
 std::vector<unsigned short> make_bf16_limbs(const std::vector<float>& w, int n_alloc, int K_pad);
 
 // Build a PackedLinear: W_src [N_src x K_src], bias [N_src] (may be empty), colvec [N_src] (may be empty)

@@ -23,6 +23,7 @@ struct TmpBuf {
     catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; } \
     return FC_OK;
 
+namespace fc { long gemm_fp16_fallbacks(); }
 namespace fc { extern int g_gemm_variant, g_gemm_stagger, g_gemm_colgroup, g_gemm_bigtile; }
 
 extern "C" {
@@ -36,6 +37,9 @@ int fc_debug_set(int32_t key, int32_t value) {
     else return FC_ERR_INVALID;
     return FC_OK;
 }
+
+/* number of calls that were repeated with the bf16-limb GEMMs because an activation left fp16's range (tests, diagnostics) */
+int64_t fc_debug_fp16_fallbacks(void) { return (int64_t)fc::gemm_fp16_fallbacks(); }
 
 int fc_op_linear_f32(const float* x, const float* W, const float* bias, const float* residual, float* y, int32_t rows, int32_t N, int32_t K,
                      int32_t act, void* stream) {
@@ -59,8 +63,9 @@ int fc_op_linear_f32(const float* x, const float* W, const float* bias, const fl
     PackedLinear L;
     L.W = wp.f(); L.bias = bp.f(); L.N_pad = np; L.K_pad = kp; L.nseg = 1; L.seg_k[0] = kp; L.n_alloc = na;
     L.n_true = N; L.k_true = K;
-    std::unique_ptr<TmpBuf> w3buf;
-    if (g_gemm_variant == 3) {                                  // split-bf16 variant: limb image via a host round trip (test path only)
+    std::unique_ptr<TmpBuf> w3buf, w2buf;
+    TmpBuf flag(sizeof(int));
+    if (g_gemm_variant == 3 || g_gemm_variant == 5) {           // split variants: limb images via a host round trip (test path only)
         FC_HIP(hipStreamSynchronize(s));
         std::vector<float> hw((size_t)na * kp);
         FC_HIP(hipMemcpy(hw.data(), wp.f(), hw.size() * 4, hipMemcpyDeviceToHost));
@@ -68,12 +73,18 @@ int fc_op_linear_f32(const float* x, const float* W, const float* bias, const fl
         w3buf.reset(new TmpBuf(w3.size() * 2));
         FC_HIP(hipMemcpy(w3buf->p, w3.data(), w3.size() * 2, hipMemcpyHostToDevice));
         L.W3 = (unsigned short*)w3buf->p;
+        const std::vector<unsigned short> w2 = make_f16_limbs(hw, na, kp);
+        if (!w2.empty()) {
+            w2buf.reset(new TmpBuf(w2.size() * 2));
+            FC_HIP(hipMemcpy(w2buf->p, w2.data(), w2.size() * 2, hipMemcpyHostToDevice));
+            L.W2 = (unsigned short*)w2buf->p;
+        }
     }
     GemmEpi e{};
     e.act = act; e.C = cp.f(); e.ldc = np;
     if (residual) { e.residual = rpad.f(); e.ldr = np; }
     ASeg a{xp.f(), kp};
-    launch_gemm(L, &a, rp, e, EPI_LINEAR, s);
+    run_fp16_guarded((int*)flag.p, s, [&] { launch_gemm(L, &a, rp, e, EPI_LINEAR, s); });
     launch_pack_rows(cp.f(), np, N, y, N, 0, N, rows, s);
     FC_HIP(hipStreamSynchronize(s));
     FC_API_END

@@ -34,6 +34,7 @@ struct FpLayer { PackedLinear lin; int cout = 0; };
 }  // namespace fc
 
 struct fc_paconv {
+    int* fp16_flag = nullptr;   // device word raised by the split-fp16 GEMM loop on an activation >= 65504 (common.h: Fp16Guard)
     fc::DeviceArena arena;
     int c_feat = 0;                       // input feature channels (input_dim - 3)
     std::vector<fc::PaLayer> sa[4];
@@ -299,7 +300,11 @@ int fc_paconv_workspace_bytes(const fc_paconv* emb, int32_t B, int32_t M, size_t
 int fc_paconv_embed_f32(fc_paconv* emb, const float* pts, float* out, int32_t B, int32_t M, void* workspace, size_t workspace_bytes, void* stream) {
     FC_API_BEGIN
     if (!emb || !workspace) throw fc::Error(FC_ERR_INVALID, "fc_paconv_embed_f32: null handle / workspace");
-    fc::paconv_forward(*emb, pts, out, B, M, workspace, workspace_bytes, (hipStream_t)stream);
+    if (!emb->fp16_flag) emb->fp16_flag = (int*)emb->arena.alloc_floats(1);
+    // fast split-fp16 GEMMs first; the whole pass is repeated with the bf16-limb GEMMs if an activation left fp16's range
+    fc::run_fp16_guarded(emb->fp16_flag, (hipStream_t)stream, [&] {
+        fc::paconv_forward(*emb, pts, out, B, M, workspace, workspace_bytes, (hipStream_t)stream);
+    });
     FC_API_END
 }
 int fc_op_fps_f32(const float* xyz, int32_t* idx, int32_t B, int32_t n, int32_t m, void* stream) {

@@ -26,7 +26,7 @@ def run(fn):
 
 
 print(f"rows={rows}")
-variants = [(int(v[0]), int(v[1:])) for v in os.environ.get("VARIANTS", "30").split(",")]   # (loop variant, big tile 0/1)
+variants = [(int(v[0]), int(v[1:])) for v in os.environ.get("VARIANTS", "50").split(",")]   # (loop variant, big tile 0/1)
 shapes = [("pre_in", 256, 150, "gelu", False), ("pre_mid", 256, 256, "gelu", True), ("pre_out", 256, 256, "none", False),
           ("q_proj", 64, 256, "none", False), ("cpl_in", 512, 214, "gelu", False), ("cpl_mid", 512, 512, "gelu", True),
           ("cpl_mid_noact", 512, 512, "none", False), ("cpl_mid_gelu", 512, 512, "gelu", False), ("cpl_mid_res", 512, 512, "none", True), ("affine_out", 300, 512, "none", False), ("spline_out", 3750, 512, "none", False),

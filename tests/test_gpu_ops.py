@@ -1,6 +1,8 @@
 """Unit-level parity of the HIP kernels, called through the C ABI (fc_op_*), against fp64 math on the host."""
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -46,29 +48,56 @@ def test_linear_is_linear_and_exact_on_integers():
     assert torch.equal(y, x @ W.t())
 
 
-def test_split_bf16_variant_matches_fp64_like_fp32():
-    """The split-bf16 GEMM main loop (3 bf16 limbs, 6 MFMAs per product block) must be as accurate as the fp32 MFMA loop."""
+def test_split_variants_match_fp64_like_fp32():
+    """The split GEMM main loops -- 2 fp16 limbs / 3 MFMAs per product block (variant 5, the default) and 3 bf16 limbs / 6 MFMAs
+    (variant 3, its unbounded-range fallback) -- must be as accurate as the fp32-input MFMA loop (variant 2)."""
     lib = engine.lib()
     try:
-        for rows, N, K, act in ((1000, 512, 512, "gelu"), (513, 3750, 512, "none"), (300, 256, 150, "none")):
-            x, W, b = _rand(rows, K, seed=1, scale=3.0), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3, scale=0.1)
+        for rows, N, K, act, xs in ((1000, 512, 512, "gelu", 3.0), (513, 3750, 512, "none", 3.0), (300, 256, 150, "none", 3.0),
+                                    (300, 64, 256, "none", 3.0), (600, 512, 512, "none", 1e-3), (600, 512, 512, "none", 300.0)):
+            x, W, b = _rand(rows, K, seed=1, scale=xs), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3, scale=0.1 * min(xs, 1.0))
             ref = torch.nn.functional.linear(x.double(), W.double(), b.double())
             if act == "gelu":
                 ref = torch.nn.functional.gelu(ref)
             errs = {}
-            for var in (2, 3):
+            for var in (2, 3, 5):
                 lib.fc_debug_set(0, var)
                 y = engine.op_linear(x.to(DEV), W.to(DEV), b.to(DEV), None, act).cpu().double()
                 errs[var] = (y - ref).abs().max().item()
-            print(f"split-bf16 {rows}x{N}x{K}: fp32-mfma err {errs[2]:.2e}  split-bf16 err {errs[3]:.2e}")
-            assert errs[3] < 2e-6 * max(1.0, K ** 0.5) and errs[3] < 4 * errs[2] + 1e-7
+            print(f"split {rows}x{N}x{K} |x|~{xs}: fp32-mfma err {errs[2]:.2e}  split-bf16 err {errs[3]:.2e}  split-fp16 err {errs[5]:.2e}")
+            for var in (3, 5):
+                assert errs[var] < 2e-6 * max(1.0, K ** 0.5) * max(xs / 3.0, 1e-3) and errs[var] < 4 * errs[2] + 1e-7 * xs
         g = torch.Generator().manual_seed(5)
         x = torch.randint(-8, 9, (384, 200), generator=g).float()
         W = torch.randint(-8, 9, (512, 200), generator=g).float()
-        lib.fc_debug_set(0, 3)
-        assert torch.equal(engine.op_linear(x.to(DEV), W.to(DEV)).cpu(), x @ W.t())      # small integers: every limb product exact
+        for var in (3, 5):
+            lib.fc_debug_set(0, var)
+            assert torch.equal(engine.op_linear(x.to(DEV), W.to(DEV)).cpu(), x @ W.t())      # small integers: every limb product exact
     finally:
-        lib.fc_debug_set(0, 3)            # shipped default
+        lib.fc_debug_set(0, 5)            # shipped default
+
+
+def test_split_fp16_out_of_range_falls_back_to_bf16_limbs():
+    """fp16 limbs cannot hold |x| >= 65504: the kernel raises its flag and the call is repeated with the bf16 limbs, so the
+    result stays fp32-accurate (and finite); weights that do not fit never get an fp16 image at all."""
+    lib = engine.lib()
+    lib.fc_debug_fp16_fallbacks.restype = ctypes.c_int64
+    x, W = _rand(300, 512, seed=1, scale=3.0), _rand(512, 512, seed=2, scale=512 ** -0.5)
+    before = lib.fc_debug_fp16_fallbacks()
+    y = engine.op_linear(x.to(DEV), W.to(DEV)).cpu().double()
+    assert lib.fc_debug_fp16_fallbacks() == before            # in range: no repeat
+    x[17, 300] = 1.0e5
+    x[250, 3] = -7.0e4
+    ref = x.double() @ W.double().t()
+    y = engine.op_linear(x.to(DEV), W.to(DEV)).cpu().double()
+    assert lib.fc_debug_fp16_fallbacks() == before + 1
+    assert torch.isfinite(y).all() and (y - ref).abs().max().item() < 2e-2 and ((y - ref).abs() / (1 + ref.abs())).max().item() < 1e-5
+    Wb = W.clone(); Wb[5, 5] = 1.0e5                          # weight out of range: bf16 limbs from the start, no repeat
+    x2 = _rand(300, 512, seed=4, scale=3.0)
+    before = lib.fc_debug_fp16_fallbacks()
+    y = engine.op_linear(x2.to(DEV), Wb.to(DEV)).cpu().double()
+    ref = x2.double() @ Wb.double().t()
+    assert lib.fc_debug_fp16_fallbacks() == before and ((y - ref).abs() / (1 + ref.abs())).max().item() < 1e-5
 
 
 @pytest.mark.parametrize("B,N,M,D", [(2, 128, 64, 64), (3, 100, 130, 64), (1, 20, 24, 32), (2, 257, 1000, 64), (1, 64, 4096, 64), (2, 40, 70, 128)])
