@@ -18,6 +18,8 @@ namespace fc {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+int g_attn_fp16 = 1;      // tuning knob (fc_debug_set 5): 0 keeps the fp32-input MFMA kernel
+
 struct AttnParams {
     const float* q; int ldq;
     const float* k; int ldk;
@@ -176,6 +178,267 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     }
 }
 
+// =====================================================================================================================
+// Split-fp16 attention (the default when the caller is inside an Fp16Guard scope, DH <= 64).
+// Same flash structure, but every product runs on the 16-bit matrix cores with fp32-equivalent operands (gemm.hip, VAR 5):
+// x = hi + lo'/2048 in two fp16 limbs, a*b ~= ah*bh + (ah*bl' + al'*bh)/2048 with the h*h products and the cross products in
+// separate fp32 accumulators.  12 MFMAs (32 cycles) per 32x32 score block instead of 32 fp32-input MFMAs (64 cycles).
+//   * K and V of the layer are split ONCE by kv_limbs_kernel into row images [key][hi DH | lo' DH] (the fp32 kernel above
+//     re-reads them per 128-query workgroup; here 32 workgroups per scene would redo the same conversion);
+//   * S^T = K Q^T: A = K rows (ds_read_b128 per limb), B = Q limbs held in registers for the whole kernel;
+//   * P: the S^T accumulator has the query on the lane and 32 keys in its registers, so registers 8s..8s+7 split into limbs
+//     ARE the A operand of k-step s of O += P V; element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3) of the block;
+//   * V: B operand wants, per lane (column d), those same 8 keys: two ds_read_b64_tr_b16 (hardware transposing read of a
+//     4-key x 16-column block per 16-lane group) on the row-major V image.  Row pitches: K 4*DH+16 B (conflict-free b128 reads),
+//     V 4*DH+64 B (the 4 rows x 64 B a half-wave's transposed read touches land on 64 distinct banks).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short v4i16 __attribute__((__vector_size__(4 * sizeof(short))));
+
+struct Attn16Params {
+    const float* q; int ldq;
+    const unsigned short* k16;      // [B * m_stride][2][DH] halves
+    const unsigned short* v16;
+    float* out; int ldo;
+    int N, n_stride, M, m_stride;
+    float qscale;
+    int* ovf;
+};
+
+// fp32 K / V columns of the projected context -> limb row images; raises *ovf on |x| >= 65504.
+__global__ __launch_bounds__(256) void kv_limbs_kernel(const float* k, int ldk, const float* v, int ldv, unsigned short* k16, unsigned short* v16,
+                                                       long rows, int DH, int* ovf) {
+    const int c4 = DH / 4;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    float amax = 0.f;
+    if (t < rows * c4) {
+        const long row = t / c4;
+        const int c = (int)(t - row * c4) * 4;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const float4 x = *reinterpret_cast<const float4*>((which ? v + row * ldv : k + row * ldk) + c);
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+            f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                amax = fmaxf(amax, fabsf(xs[e]));
+                h[e] = (_Float16)xs[e];
+                l[e] = (_Float16)((xs[e] - (float)h[e]) * 2048.0f);
+            }
+            unsigned short* dst = (which ? v16 : k16) + row * 2 * DH + c;
+            *reinterpret_cast<f16x4*>(dst) = h;
+            *reinterpret_cast<f16x4*>(dst + DH) = l;
+        }
+    }
+    if (amax >= 65504.0f) atomicOr(ovf, 1);
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn16_kernel(const Attn16Params p) {
+    constexpr int KS = DH / 16, DT = DH / 32;
+    constexpr int KP = 4 * DH + 16, VP = 4 * DH + 64;          // LDS row pitches in bytes
+    constexpr int VOFF = 64 * KP;
+    constexpr int STAGE = 64 * (KP + VP);
+    constexpr int CPR = DH / 4;                                // 16-byte chunks per image row
+    constexpr int NCH = 64 * CPR / 256;                        // chunks per thread, tile and image
+    extern __shared__ float smem[];
+    char* smc = reinterpret_cast<char*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    // ---- Q limbs of this lane's query (B operand of S^T = K Q^T): element j of k-step s is q[16 s + 8 h + j]
+    f16x8 qh[KS], ql[KS];
+    float amax = 0.f;
+    {
+        int qi = q0 + li;
+        qi = qi < p.N ? qi : p.N - 1;
+        const float* qp = p.q + ((size_t)b * p.n_stride + qi) * p.ldq + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * s), t1 = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
+            const float xs[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = xs[e] * p.qscale;
+                amax = fmaxf(amax, fabsf(x));
+                qh[s][e] = (_Float16)x;
+                ql[s][e] = (_Float16)((x - (float)qh[s][e]) * 2048.0f);
+            }
+        }
+    }
+    if (amax >= 65504.0f) atomicOr(p.ovf, 1);
+
+    floatx16 om[DT], oc[DT];                                   // main (h*h) and cross-product accumulators of O
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { om[d][r] = 0.f; oc[d][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- staging: plain 16-byte copies of the limb images (whole-vector register values: arrays went through scratch)
+    typedef unsigned int u32xs __attribute__((ext_vector_type(4 * NCH)));
+    u32xs rk, rv;
+    const uint4* kb = reinterpret_cast<const uint4*>(p.k16) + (size_t)b * p.m_stride * CPR;
+    const uint4* vb = reinterpret_cast<const uint4*>(p.v16) + (size_t)b * p.m_stride * CPR;
+#define FC_GLOAD(T_)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                         \
+        const int c_ = tid + 256 * i, kr_ = c_ / CPR, part_ = c_ - kr_ * CPR;                 \
+        int key_ = (T_) * 64 + kr_;                                                           \
+        key_ = key_ < p.M ? key_ : p.M - 1; /* clamped rows are masked to -inf below */       \
+        const uint4 a_ = kb[(size_t)key_ * CPR + part_], b_ = vb[(size_t)key_ * CPR + part_];  \
+        rk[4 * i] = a_.x; rk[4 * i + 1] = a_.y; rk[4 * i + 2] = a_.z; rk[4 * i + 3] = a_.w;     \
+        rv[4 * i] = b_.x; rv[4 * i + 1] = b_.y; rv[4 * i + 2] = b_.z; rv[4 * i + 3] = b_.w;     \
+    }
+#define FC_LSTORE(ST_)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                         \
+        const int c_ = tid + 256 * i, kr_ = c_ / CPR, part_ = c_ - kr_ * CPR;                 \
+        *reinterpret_cast<uint4*>(smc + (ST_) * STAGE + kr_ * KP + part_ * 16) =              \
+            make_uint4(rk[4 * i], rk[4 * i + 1], rk[4 * i + 2], rk[4 * i + 3]);               \
+        *reinterpret_cast<uint4*>(smc + (ST_) * STAGE + VOFF + kr_ * VP + part_ * 16) =       \
+            make_uint4(rv[4 * i], rv[4 * i + 1], rv[4 * i + 2], rv[4 * i + 3]);               \
+    }
+
+    // transposed-read address of this lane inside a [4 keys][16 columns] block: lane 4q+p of a 16-lane group supplies row q,
+    // columns 4p..4p+3; the group's 16 columns are 16*((lane>>4)&1) .. +15 of the 32-column block, its keys start at 4*lh
+    const int tr_off = (4 * lh + ((lane & 15) >> 2)) * VP + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+    const int ntiles = (p.M + 63) / 64;
+    FC_GLOAD(0)
+    FC_LSTORE(0)
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int tn = t + 1 < ntiles ? t + 1 : t;          // the last iteration re-loads its own tile: branch-free loop
+        FC_GLOAD(tn)
+        const char* sK = smc + (t & 1) * STAGE;
+        const char* sV = sK + VOFF;
+
+        // ---- S^T = K Q^T for the two 32-key halves of the tile
+        floatx16 s[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            floatx16 sm, sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; }
+            const char* kr = sK + (32 * h2 + li) * KP + 16 * lh;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(kr + 32 * ks);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(kr + 2 * DH + 32 * ks);
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sm, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[h2][r] = sm[r] + sc[r] * (1.0f / 2048.0f);
+        }
+        // ---- mask the tail keys of the last tile
+        if (t * 64 + 64 > p.M) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + 32 * h2 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= p.M) s[h2][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (this lane's query = lane&31; the other half of its keys lives in lane^32)
+        float mt = s[0][0];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[h2][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp2f(m_run - m_new);          // 0 on the first tile (m_run = -inf)
+        float lt = 0.f;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f(s[h2][r] - m_new);
+                s[h2][r] = pv;
+                lt += pv;
+            }
+        lt += __shfl_xor(lt, 32, 64);
+        l_run = l_run * alpha + lt;
+        m_run = m_new;
+        // ---- rescale O: its rows are queries (r&3)+8(r>>2)+4h, whose alpha lives in that LANE
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) { om[d][r] *= ar; oc[d][r] *= ar; }
+            }
+        }
+        // ---- O += P V, 16 keys per MFMA k-step: A = limbs of P registers 8 s2 .. 8 s2 + 7, B = V via transposed reads
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = s[h2][8 * s2 + j];
+                    ph[j] = (_Float16)x;
+                    pl[j] = (_Float16)((x - (float)ph[j]) * 2048.0f);
+                }
+                const char* vr = sV + (32 * h2 + 16 * s2) * VP + tr_off;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    // (assembled with one shufflevector + whole-vector bit_cast: element-wise extraction of the read's result made hipcc
+                    //  emit v_perm/v_mov sequences that duplicated its first dword)
+#define FC_TR(OFF_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(vr + (OFF_)))
+                    const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(64 * d), FC_TR(8 * VP + 64 * d), 0, 1, 2, 3, 4, 5, 6, 7));
+                    const f16x8 vl = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(64 * d + 2 * DH), FC_TR(8 * VP + 64 * d + 2 * DH),
+                                                                                      0, 1, 2, 3, 4, 5, 6, 7));
+#undef FC_TR
+                    om[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, om[d], 0, 0, 0);
+                    oc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, oc[d], 0, 0, 0);
+                    oc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oc[d], 0, 0, 0);
+                }
+            }
+        }
+        FC_LSTORE((t + 1) & 1)
+        __syncthreads();
+    }
+#undef FC_GLOAD
+#undef FC_LSTORE
+
+    // ---- normalise and store: O rows are queries (r&3)+8(r>>2)+4h of this wave, columns d = 32*dt + lane&31
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float lr = __shfl(l_run, qr, 64);
+        const int qi = q0 + qr;
+        if (qi < p.N) {
+            float* op = p.out + ((size_t)b * p.n_stride + qi) * p.ldo + li;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) op[32 * d] = (om[d][r] + oc[d][r] * (1.0f / 2048.0f)) / lr;
+        }
+    }
+}
+
+template <int DH>
+static void launch_attn16_dh(const Attn16Params& p, int B, hipStream_t s) {
+    constexpr size_t lds = 2 * 64 * (size_t)(8 * DH + 80);
+    static bool attr_done = false;
+    auto kern = attn16_kernel<DH>;
+    if (!attr_done) {
+        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    char name[64];
+    snprintf(name, sizeof name, "void fc::attn16_kernel<%d>(fc::Attn16Params)", DH);
+    ProfScope ps(name, 4.0 * B * (double)p.N * (double)p.M * DH, 0.0, s);
+    hipLaunchKernelGGL(kern, dim3((p.N + 127) / 128, B), dim3(256), lds, s, p);
+    FC_HIP(hipGetLastError());
+}
+
 template <int DH>
 static void launch_attn_dh(const AttnParams& p, int B, hipStream_t s) {
     constexpr size_t lds = 2 * 2 * 64 * (size_t)(DH + 4) * sizeof(float);
@@ -193,10 +456,27 @@ static void launch_attn_dh(const AttnParams& p, int B, hipStream_t s) {
 }
 
 static void launch_attention_scaled(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
-                                    int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, float qscale, hipStream_t s) {
+                                    int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, float qscale, void* limb_ws,
+                                    hipStream_t s) {
     if (B <= 0 || N <= 0 || M <= 0) throw Error(FC_ERR_INVALID, "attention: empty problem");
     if ((ldq | ldk | ldv) % 4 != 0 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15))
         throw Error(FC_ERR_INVALID, "attention: q/k/v must be 16-byte aligned with pitches that are multiples of 4 floats");
+    int* flag = gemm_fp16_flag();
+    if (flag && limb_ws && dh_pad <= 64 && g_attn_fp16) {
+        // split-fp16 path (needs the caller's Fp16Guard scope for its range check and limb_ws for the K/V limb images)
+        const long rows = (long)(B - 1) * m_stride_rows + M;
+        unsigned short* k16 = (unsigned short*)limb_ws;
+        unsigned short* v16 = k16 + (size_t)rows * 2 * dh_pad;
+        {
+            ProfScope ps("fc::kv_limbs_kernel", 0.0, (double)rows * dh_pad * 16.0, s);
+            const long n = rows * (dh_pad / 4);
+            hipLaunchKernelGGL(kv_limbs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, ldk, v, ldv, k16, v16, rows, dh_pad, flag);
+            FC_HIP(hipGetLastError());
+        }
+        Attn16Params p{q, ldq, k16, v16, out, ldo, N, n_stride_rows, M, m_stride_rows, qscale, flag};
+        if (dh_pad == 32) launch_attn16_dh<32>(p, B, s); else launch_attn16_dh<64>(p, B, s);
+        return;
+    }
     AttnParams p{q, ldq, k, ldk, v, ldv, out, ldo, N, n_stride_rows, M, m_stride_rows, qscale};
     switch (dh_pad) {
         case 32: launch_attn_dh<32>(p, B, s); break;
@@ -206,15 +486,17 @@ static void launch_attention_scaled(const float* q, int ldq, const float* k, int
     }
 }
 
+size_t attention_limb_ws_bytes(long kv_rows, int dh_pad) { return dh_pad <= 64 ? (size_t)kv_rows * dh_pad * 8 : 0; }
+
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
-                      int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, hipStream_t s) {
-    launch_attention_scaled(q, ldq, k, ldk, v, ldv, out, ldo, B, N, n_stride_rows, M, m_stride_rows, dh_pad, 1.0f, s);
+                      int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, void* limb_ws, hipStream_t s) {
+    launch_attention_scaled(q, ldq, k, ldk, v, ldv, out, ldo, B, N, n_stride_rows, M, m_stride_rows, dh_pad, 1.0f, limb_ws, s);
 }
 
 void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale,
-                         hipStream_t s) {
+                         void* limb_ws, hipStream_t s) {
     launch_attention_scaled(q, dh_pad, k, dh_pad, v, dh_pad, out, dh_pad, B, N, N, M, M, dh_pad,
-                            scale * 1.4426950408889634f, s);
+                            scale * 1.4426950408889634f, limb_ws, s);
 }
 
 }  // namespace fc

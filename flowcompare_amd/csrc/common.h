@@ -139,6 +139,7 @@ struct Fp16Guard {
     int* flag; hipStream_t stream; bool open;
 };
 bool gemm_fp16_enabled();
+int* gemm_fp16_flag();         // the open scope's device flag of the calling thread, or null
 template <class F>
 inline void run_fp16_guarded(int* dev_flag, hipStream_t s, F&& fn) {
     if (!dev_flag || !gemm_fp16_enabled()) { fn(); return; }
@@ -154,10 +155,13 @@ void launch_pack_rows(const float* src, int src_ld, int src_cols, float* dst, in
 void launch_fill(float* p, float v, size_t n, hipStream_t s);
 void launch_repeat_extra(const float* extra, int X, float* rowscal, int B, int N, hipStream_t s);
 void launch_layernorm(float* h, int ld, int width, int rows, hipStream_t s);   // in place, no affine (folded into q-proj)
+// limb_ws: scratch of attention_limb_ws_bytes(rows of k/v, dh_pad) bytes for the split-fp16 kernel's K/V limb images; with a null
+// limb_ws, outside an Fp16Guard scope or for dh_pad > 64 the fp32-input MFMA kernel runs
+size_t attention_limb_ws_bytes(long kv_rows, int dh_pad);
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
-                      int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, hipStream_t s);
+                      int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, void* limb_ws, hipStream_t s);
 void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale,
-                         hipStream_t s);
+                         void* limb_ws, hipStream_t s);
 void launch_base_density(const float* x, int ldx, int d1, int d1_pad, int d2, float* logprob, float log_const,
                          float* z_out, int D, int rows, hipStream_t s);
 void launch_spline(const float* params, int ldp, int d2s, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows,

@@ -421,6 +421,7 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
 // ---------------------------------------------------------------- workspace plan
 struct FlowWs {
     float *xa, *xb, *h[3], *q, *a, *ctxp, *kv, *xin, *rowscal, *spl, *cbuf;
+    void* kv16;      // K / V limb images of the layer in flight (split-fp16 attention)
     int P, P_pad, Pc, Pc_pad, ldkv;
 };
 static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t bytes, bool dry, size_t* need) {
@@ -441,6 +442,7 @@ static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t by
     w.rowscal = c.floats((size_t)w.P_pad);
     w.spl = c.floats(d.ldp ? (size_t)w.P_pad * d.ldp : 1);
     w.cbuf = c.floats(d.nz > 0 ? (size_t)w.P_pad * d.nz_pad : 1);
+    w.kv16 = c.bytes(f.n_attn > 0 ? std::max<size_t>(attention_limb_ws_bytes(w.Pc_pad, d.I_pad), 16) : 16);
     if (need) *need = c.off + 256;
     return w;
 }
@@ -466,7 +468,7 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
     eq.act = FC_ACT_NONE; eq.C = w.q; eq.ldc = d.I_pad; eq.rows_valid = w.P;
     ASeg aq{w.h[o], ldh};
     launch_gemm(at.q, &aq, w.P_pad, eq, EPI_LINEAR, s);
-    launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad, s);
+    launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad, w.kv16, s);
 }
 
 // the conditioned coupling of one block (PreConditionApplier, models/transform.py:47-58), forward or inverse, in place on xc

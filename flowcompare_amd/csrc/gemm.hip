@@ -517,6 +517,7 @@ static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
 
 bool gemm_fp16_enabled() { return g_gemm_variant == 5; }
+int* gemm_fp16_flag() { return g_gemm_variant == 5 ? t_fp16_flag : nullptr; }
 long gemm_fp16_fallbacks() { return g_fp16_fallbacks.load(); }
 Fp16Guard::Fp16Guard(int* dev_flag, hipStream_t s) : flag(dev_flag), stream(s), open(true) {
     FC_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));

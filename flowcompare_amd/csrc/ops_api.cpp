@@ -6,7 +6,6 @@
 #include "hostpack.h"
 
 namespace fc {
-void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale, hipStream_t s);
 
 struct TmpBuf {
     void* p = nullptr;
@@ -24,7 +23,7 @@ struct TmpBuf {
     return FC_OK;
 
 namespace fc { long gemm_fp16_fallbacks(); }
-namespace fc { extern int g_gemm_variant, g_gemm_stagger, g_gemm_colgroup, g_gemm_bigtile; }
+namespace fc { extern int g_gemm_variant, g_gemm_stagger, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16; }
 
 extern "C" {
 
@@ -34,6 +33,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 1) fc::g_gemm_stagger = value;
     else if (key == 2) fc::g_gemm_colgroup = value;
     else if (key == 3) fc::g_gemm_bigtile = value;
+    else if (key == 5) fc::g_attn_fp16 = value;
     else return FC_ERR_INVALID;
     return FC_OK;
 }
@@ -95,7 +95,10 @@ int fc_op_attention_f32(const float* q, const float* k, const float* v, float* o
     FC_API_BEGIN
     if (!q || !k || !v || !out) throw fc::Error(FC_ERR_INVALID, "fc_op_attention_f32: null pointer");
     if (D != 32 && D != 64 && D != 128) throw fc::Error(FC_ERR_UNSUPPORTED, "fc_op_attention_f32: D must be 32, 64 or 128");
-    fc::launch_attention_op(q, k, v, out, B, N, M, D, scale, (hipStream_t)stream);
+    fc::TmpBuf limbs(fc::attention_limb_ws_bytes((long)B * M, D)), flag(sizeof(int));
+    fc::run_fp16_guarded((int*)flag.p, (hipStream_t)stream,
+                         [&] { fc::launch_attention_op(q, k, v, out, B, N, M, D, scale, limbs.p, (hipStream_t)stream); });
+    FC_HIP(hipStreamSynchronize((hipStream_t)stream));
     FC_API_END
 }
 

@@ -102,12 +102,40 @@ def test_split_fp16_out_of_range_falls_back_to_bf16_limbs():
 
 @pytest.mark.parametrize("B,N,M,D", [(2, 128, 64, 64), (3, 100, 130, 64), (1, 20, 24, 32), (2, 257, 1000, 64), (1, 64, 4096, 64), (2, 40, 70, 128)])
 def test_attention_matches_fp64(B, N, M, D):
+    """Both attention kernels: split-fp16 (default for D <= 64) and the fp32-input MFMA kernel (D = 128, fallback)."""
     q, k, v = _rand(B, N, D, seed=1, scale=2.0), _rand(B, M, D, seed=2, scale=2.0), _rand(B, M, D, seed=3)
     scale = D ** -0.5
-    out = engine.op_attention(q.to(DEV), k.to(DEV), v.to(DEV), scale).cpu().double()
     w = torch.softmax(q.double() @ k.double().transpose(1, 2) * scale, -1)
     ref = w @ v.double()
-    assert (out - ref).abs().max().item() < 5e-6
+    lib = engine.lib()
+    try:
+        for fp16 in (1, 0):
+            lib.fc_debug_set(5, fp16)
+            out = engine.op_attention(q.to(DEV), k.to(DEV), v.to(DEV), scale).cpu().double()
+            assert (out - ref).abs().max().item() < 5e-6, f"attention kernel fp16={fp16}"
+    finally:
+        lib.fc_debug_set(5, 1)
+
+
+def test_attention_key_order_and_out_of_range_fallback():
+    """Uniform scores over v[j] = j + d/1000 give the mean key exactly only if every key is paired with its own probability
+    (a wrong k-order in the P V product passes random tests with small error but not this); then an out-of-range key makes
+    the split-fp16 kernel raise its flag and the call is repeated with the fp32-input kernel."""
+    lib = engine.lib()
+    lib.fc_debug_fp16_fallbacks.restype = ctypes.c_int64
+    B, N, M, D = 2, 100, 130, 64
+    v = torch.arange(M).float()[None, :, None].expand(B, M, D).contiguous() + torch.arange(D).float()[None, None, :] * 1e-3
+    k = _rand(B, M, D, seed=2)
+    before = lib.fc_debug_fp16_fallbacks()
+    out = engine.op_attention(torch.zeros(B, N, D).to(DEV), k.to(DEV), v.to(DEV), 0.125).cpu().double()
+    assert (out - v.double().mean(1, keepdim=True)).abs().max().item() < 2e-5
+    assert lib.fc_debug_fp16_fallbacks() == before
+    q = _rand(B, N, D, seed=1)
+    k[1, 77, 5] = 9.0e4
+    ref = torch.softmax(q.double() @ k.double().transpose(1, 2) * 0.125, -1) @ v.double()
+    out = engine.op_attention(q.to(DEV), k.to(DEV), v.to(DEV), 0.125).cpu().double()
+    assert lib.fc_debug_fp16_fallbacks() == before + 1
+    assert (out - ref).abs().max().item() < 2e-4
 
 
 def test_attention_spiked_scores_force_rescale():
