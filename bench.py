@@ -193,6 +193,15 @@ def main():
             achieved = dom["bytes"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+        # HBM bytes per launch of that kernel from the committed PMC passes of this same command (profiles/pmc_summary.py: separate
+        # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction); PMC cannot be collected inside a timed run
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(dom["kernel"])
+            if pmc and args.config == "c2_dgcnn_attn_spline" and B == 16 and N == 4096 and not args.layers:
+                roof["traffic"] = pmc["hbm_bytes_per_launch"]
+                roof["traffic_unit"] = "HBM bytes per launch (profiles/pmc_traffic.json)"
+        except (OSError, KeyError, ValueError):
+            pass
         roof.update({"avg_launch_ms": per_launch_ms, "launches": dom["launches"], "share_of_gpu_time": dom["ms"] / tot_ms,
                      "flops_counted": "useful multiply-adds of the launches (padding excluded), HIP events on the launch stream"})
         alg = ALG_MFLOP_PER_POINT.get(args.config)

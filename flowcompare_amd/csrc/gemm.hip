@@ -209,15 +209,19 @@ void gemm_f32_kernel(const GemmParams p) {
         // (5.3x the fp32-input matrix rate), 4 bytes per LDS element instead of 6.  fp16 overflows at 65504: every staged |x| is
         // max-reduced and a launch that met one >= 65504 raises *p.ovf; the entry point then repeats the whole call with the
         // bf16 limbs (unbounded range).  Weights with such entries never get an fp16 image (PackedLinear.W2 == nullptr).
-        constexpr bool F16 = VAR == 5;
+        constexpr bool F16 = VAR >= 5;
+        constexpr int KS = VAR == 6 ? 32 : 16;                      // k extent of one LDS stage (VAR 6: experiment, one-deep prefetch)
+        constexpr int KSUB = KS / 16, U = 32 / KS;
         constexpr int NL = F16 ? 2 : 3;                             // limbs
-        constexpr int ROWB = NL * 32 + 16;                          // bytes per LDS row (16 B pad: conflict-free 16-byte fragment reads)
-        constexpr int CH = NL * 2;                                  // 16-byte chunks per (row, k tile) of a limb image
+        constexpr int LIMB_B = KS * 2;                              // bytes of one limb of a row
+        constexpr int ROWB = NL * LIMB_B + 16;                      // bytes per LDS row (16 B pad: conflict-free 16-byte fragment reads)
+        constexpr int CH = NL * KS / 8;                             // 16-byte chunks per (row, stage) of a limb image
         constexpr int STAGE3 = (BM + BN) * ROWB;
-        constexpr int A3 = BM * 4 / NT, W3N = (BN * CH + NT - 1) / NT, RPP3 = NT / 4;   // float4 loads of A, 16-byte loads of W per thread and tile
+        constexpr int TPR = KS / 4;                                 // threads (float4s) per A row
+        constexpr int RPP3 = NT / TPR, A3 = BM / RPP3, W3N = (BN * CH + NT - 1) / NT;   // float4 loads of A, 16-byte loads of W per thread and stage
         char* smc = reinterpret_cast<char*>(smem);
-        const int lrow3 = tid >> 2, lc3 = (tid & 3) * 4;
-        const int KT16 = p.KT * 2;
+        const int lrow3 = tid / TPR, lc3 = (tid % TPR) * 4;
+        const int KT16 = p.KT * 2, KTS = p.KT * U;
         const unsigned short* const Wl = F16 ? p.W2 : p.W3;
         float amax = 0.f;
         // two register sets: the tile loaded in iteration kt is only converted/stored in iteration kt+1, so a global load has a
@@ -229,23 +233,24 @@ void gemm_f32_kernel(const GemmParams p) {
         {                                                                                                          \
             const float* Ap_ = p.A[0];                                                                             \
             int lda_ = p.lda[0], kk_ = (KT_);                                                                      \
-            if (kk_ >= 2 * p.kt[0]) {                                                                              \
-                kk_ -= 2 * p.kt[0]; Ap_ = p.A[1]; lda_ = p.lda[1];                                                 \
-                if (kk_ >= 2 * p.kt[1]) { kk_ -= 2 * p.kt[1]; Ap_ = p.A[2]; lda_ = p.lda[2]; }                     \
+            if (kk_ >= U * p.kt[0]) {                                                                              \
+                kk_ -= U * p.kt[0]; Ap_ = p.A[1]; lda_ = p.lda[1];                                                 \
+                if (kk_ >= U * p.kt[1]) { kk_ -= U * p.kt[1]; Ap_ = p.A[2]; lda_ = p.lda[2]; }                     \
             }                                                                                                      \
-            const float* a_ = Ap_ + (size_t)(m0 + lrow3) * lda_ + kk_ * 16 + lc3;                                  \
+            const float* a_ = Ap_ + (size_t)(m0 + lrow3) * lda_ + kk_ * KS + lc3;                                  \
             _Pragma("unroll") for (int i = 0; i < A3; ++i) ra3_##S_[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(RPP3 * i) * lda_); \
             _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
                 int c_ = tid + NT * i;                                                                             \
                 c_ = c_ < BN * CH ? c_ : BN * CH - 1;     /* unconditional load (a guarded one sends the staging registers through scratch) */ \
                 const int row_ = c_ / CH, part_ = c_ - row_ * CH;                                                  \
-                const uint4 t_ = *reinterpret_cast<const uint4*>(Wl + ((size_t)(n0 + row_) * KT16 + (KT_)) * (NL * 16) + part_ * 8); \
+                const int sub_ = part_ / (NL * 2), q2_ = part_ - sub_ * (NL * 2);   /* k16 tile of the stage; limb*2 + half */ \
+                const uint4 t_ = *reinterpret_cast<const uint4*>(Wl + ((size_t)(n0 + row_) * KT16 + (KT_) * KSUB + sub_) * (NL * 16) + q2_ * 8); \
                 rw3_##S_[4 * i] = t_.x; rw3_##S_[4 * i + 1] = t_.y; rw3_##S_[4 * i + 2] = t_.z; rw3_##S_[4 * i + 3] = t_.w; \
             }                                                                                                      \
         }
 #define FC_LSTORE3(S_, ST_)                                                                                          \
         {                                                                                                          \
-            char* sa_ = smc + (ST_) * STAGE3 + lrow3 * ROWB + (tid & 3) * 8;                                        \
+            char* sa_ = smc + (ST_) * STAGE3 + lrow3 * ROWB + (tid % TPR) * 8;                                      \
             _Pragma("unroll") for (int i = 0; i < A3; ++i) {                                                       \
                 const float x_[4] = {ra3_##S_[i].x, ra3_##S_[i].y, ra3_##S_[i].z, ra3_##S_[i].w};                  \
                 if constexpr (F16) {                                                                               \
@@ -256,7 +261,7 @@ void gemm_f32_kernel(const GemmParams p) {
                         l_[e_] = (_Float16)((x_[e_] - (float)h_[e_]) * 2048.0f);                                   \
                     }                                                                                              \
                     *reinterpret_cast<f16x4*>(sa_ + RPP3 * i * ROWB) = h_;                                          \
-                    *reinterpret_cast<f16x4*>(sa_ + RPP3 * i * ROWB + 32) = l_;                                     \
+                    *reinterpret_cast<f16x4*>(sa_ + RPP3 * i * ROWB + LIMB_B) = l_;                                 \
                 } else {                                                                                           \
                     bf16x4 h_, m_, l_;                                                                             \
                     _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                             \
@@ -266,27 +271,28 @@ void gemm_f32_kernel(const GemmParams p) {
                         l_[e_] = (__bf16)(r1_ - (float)m_[e_]);                                                    \
                     }                                                                                              \
                     *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB) = h_;                                         \
-                    *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB + 32) = m_;                                    \
-                    *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB + 64) = l_;                                    \
+                    *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB + LIMB_B) = m_;                                \
+                    *reinterpret_cast<bf16x4*>(sa_ + RPP3 * i * ROWB + 2 * LIMB_B) = l_;                            \
                 }                                                                                                  \
             }                                                                                                      \
             _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
                 const int c_ = tid + NT * i, row_ = c_ / CH, part_ = c_ - row_ * CH;                               \
+                const int sub_ = part_ / (NL * 2), q2_ = part_ - sub_ * (NL * 2);                                  \
                 if (BN * CH % NT == 0 || c_ < BN * CH)                                                             \
-                    *reinterpret_cast<uint4*>(smc + (ST_) * STAGE3 + (BM + row_) * ROWB + part_ * 16) =                    \
+                    *reinterpret_cast<uint4*>(smc + (ST_) * STAGE3 + (BM + row_) * ROWB + (q2_ >> 1) * LIMB_B + sub_ * 32 + (q2_ & 1) * 16) = \
                         make_uint4(rw3_##S_[4 * i], rw3_##S_[4 * i + 1], rw3_##S_[4 * i + 2], rw3_##S_[4 * i + 3]);   \
             }                                                                                                      \
         }
 #define FC_MMA3(ST_)                                                                                              \
-        {                                                                                                          \
-            const char* sA = smc + (ST_) * STAGE3 + (wr * TM * 32 + li) * ROWB + lh * 16;                           \
-            const char* sB = smc + (ST_) * STAGE3 + (BM + wc * TN * 32 + li) * ROWB + lh * 16;                      \
+        _Pragma("unroll") for (int sub = 0; sub < KSUB; ++sub) {                                                   \
+            const char* sA = smc + (ST_) * STAGE3 + (wr * TM * 32 + li) * ROWB + lh * 16 + sub * 32;                \
+            const char* sB = smc + (ST_) * STAGE3 + (BM + wc * TN * 32 + li) * ROWB + lh * 16 + sub * 32;           \
             if constexpr (F16) {                                                                                   \
                 f16x8 af3[TM][2], bf3[TN][2];                                                                      \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
-                    _Pragma("unroll") for (int q = 0; q < 2; ++q) af3[i][q] = *reinterpret_cast<const f16x8*>(sA + i * 32 * ROWB + q * 32); \
+                    _Pragma("unroll") for (int q = 0; q < 2; ++q) af3[i][q] = *reinterpret_cast<const f16x8*>(sA + i * 32 * ROWB + q * LIMB_B); \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
-                    _Pragma("unroll") for (int q = 0; q < 2; ++q) bf3[j][q] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + q * 32); \
+                    _Pragma("unroll") for (int q = 0; q < 2; ++q) bf3[j][q] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + q * LIMB_B); \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
                     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af3[i][0], bf3[j][0], acc[i][j], 0, 0, 0);     /* hi * hi */  \
@@ -296,9 +302,9 @@ void gemm_f32_kernel(const GemmParams p) {
             } else {                                                                                               \
                 bf16x8 af3[TM][3], bf3[TN][3];                                                                     \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
-                    _Pragma("unroll") for (int q = 0; q < 3; ++q) af3[i][q] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * ROWB + q * 32); \
+                    _Pragma("unroll") for (int q = 0; q < 3; ++q) af3[i][q] = *reinterpret_cast<const bf16x8*>(sA + i * 32 * ROWB + q * LIMB_B); \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
-                    _Pragma("unroll") for (int q = 0; q < 3; ++q) bf3[j][q] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * ROWB + q * 32); \
+                    _Pragma("unroll") for (int q = 0; q < 3; ++q) bf3[j][q] = *reinterpret_cast<const bf16x8*>(sB + j * 32 * ROWB + q * LIMB_B); \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
                     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af3[i][2], bf3[j][0], acc[i][j], 0, 0, 0);   /* lo * hi */   \
@@ -319,21 +325,34 @@ void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) corr[i][j][r] = 0.f;
         }
-        // KT16 is even (K_pad is a multiple of 32).  Stage s of LDS holds tile kt (s = kt & 1); register set s holds tile kt+1 ... kt+2.
-        FC_GLOAD3(0, 0)
-        FC_LSTORE3(0, 0)
-        FC_GLOAD3(1, 1)
-        __syncthreads();
-        for (int kt = 0; kt < KT16; kt += 2) {
-            const int k2 = kt + 2 < KT16 ? kt + 2 : KT16 - 1, k3 = kt + 3 < KT16 ? kt + 3 : KT16 - 1;   // tail re-loads: branch-free loop
-            FC_GLOAD3(0, k2)
-            FC_MMA3(0)
-            FC_LSTORE3(1, 1)
+        if constexpr (KS == 16) {
+            // KT16 is even (K_pad is a multiple of 32).  Stage s of LDS holds tile kt (s = kt & 1); register set s holds tile kt+1 ... kt+2.
+            FC_GLOAD3(0, 0)
+            FC_LSTORE3(0, 0)
+            FC_GLOAD3(1, 1)
             __syncthreads();
-            FC_GLOAD3(1, k3)
-            FC_MMA3(1)
+            for (int kt = 0; kt < KT16; kt += 2) {
+                const int k2 = kt + 2 < KT16 ? kt + 2 : KT16 - 1, k3 = kt + 3 < KT16 ? kt + 3 : KT16 - 1;   // tail re-loads: branch-free loop
+                FC_GLOAD3(0, k2)
+                FC_MMA3(0)
+                FC_LSTORE3(1, 1)
+                __syncthreads();
+                FC_GLOAD3(1, k3)
+                FC_MMA3(1)
+                FC_LSTORE3(0, 0)
+                __syncthreads();
+            }
+        } else {
+            FC_GLOAD3(0, 0)
             FC_LSTORE3(0, 0)
             __syncthreads();
+            for (int kt = 0; kt < KTS; ++kt) {
+                const int ktn = kt + 1 < KTS ? kt + 1 : kt;
+                FC_GLOAD3(0, ktn)
+                FC_MMA3(kt & 1)
+                FC_LSTORE3(0, (kt + 1) & 1)
+                __syncthreads();
+            }
         }
         if constexpr (F16) {
 #pragma unroll
@@ -511,7 +530,7 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 5, g_gemm_stagger = 0, g_gemm_colgroup = 10, g_gemm_bigtile = 0;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 5, g_gemm_stagger = 0, g_gemm_colgroup = 10, g_gemm_bigtile = 1, g_gemm_k32 = 0;     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
@@ -536,7 +555,7 @@ bool Fp16Guard::overflowed() {
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds = VAR == 5 ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds = VAR == 6 ? 2 * (size_t)(BM + BN) * 144 : VAR == 5 ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, EPI, VAR>;
     if (!attr_done) {
@@ -589,10 +608,15 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             else launch_cfg<128, 64, 4, 1, EPI_LINEAR>(p, s);
         } else if (L.N_pad % 128 == 0 || L.N_pad > 320 || (split && L.n_alloc >= round_up(L.N_pad, 128))) {
             // (with the split-bf16 loop two co-resident 128x128 workgroups beat the one-wave-per-SIMD 128x320 tile even at N = 320)
-            if (split && g_gemm_bigtile && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 3>(p, s); }
+            // 8-wave 256x128 workgroups for the wide layers (N >= 1024, e.g. the 3750-column spline parameter layer: +3 % measured);
+            // knob 3: 0 = never, 1 = wide layers (default), 2 = every layer
+            const bool big = g_gemm_bigtile == 2 || (g_gemm_bigtile == 1 && L.N_pad >= 1024);
+            if (f16 && big && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 5>(p, s); }
+            else if (split && g_gemm_bigtile == 2 && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 3>(p, s); }
             else {
                 p.nbm = rows_alloc / 128;
-                if (f16) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 5>(p, s);
+                if (f16 && g_gemm_k32) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 6>(p, s);
+                else if (f16) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 5>(p, s);
                 else if (split) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 3>(p, s);
                 else if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
                 else if (g_gemm_variant == 1) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 1>(p, s);
