@@ -158,6 +158,12 @@ void launch_layernorm(float* h, int ld, int width, int rows, hipStream_t s);   /
 // limb_ws: scratch of attention_limb_ws_bytes(rows of k/v, dh_pad) bytes for the split-fp16 kernel's K/V limb images; with a null
 // limb_ws, outside an Fp16Guard scope or for dh_pad > 64 the fp32-input MFMA kernel runs
 size_t attention_limb_ws_bytes(long kv_rows, int dh_pad);
+// staging.hip: the steps either side of the path
+void launch_fps_nd(const float* pts, int ld, int C, int64_t* idx, int B, int n, int m, float* dist_scratch, hipStream_t s);
+void launch_co_unit_sphere(const float* p0, int n0, const float* p1, int n1, int ld, float* o0, float* o1, float* inverse, int B, hipStream_t s);
+void launch_clamp_infs(float* t, long n, float* stats4, int* status, hipStream_t s);
+void launch_change_map(float* lp10, int N, float* lp00, int N0, float* out, int B, float multiple, float hard_cutoff, int use_cutoff,
+                       float* stats4, int* status, hipStream_t s);
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                       int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, void* limb_ws, hipStream_t s);
 void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale,

@@ -116,6 +116,46 @@ int fc_op_knn_f32(const float* f, int32_t* idx, int32_t B, int32_t M, int32_t C,
     FC_API_END
 }
 
+int fc_stage_fps_f32(const float* pts, int32_t ld, int32_t C, int64_t* idx, int32_t B, int32_t n, int32_t m, void* stream) {
+    FC_API_BEGIN
+    if (!pts || !idx || B < 1 || n < 1 || m < 1) throw fc::Error(FC_ERR_INVALID, "fc_stage_fps_f32: bad argument");
+    fc::TmpBuf scratch(n > 24576 ? (size_t)B * n * sizeof(float) : 4);
+    fc::launch_fps_nd(pts, ld, C, idx, B, n, m, scratch.f(), (hipStream_t)stream);
+    FC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    FC_API_END
+}
+
+int fc_stage_co_unit_sphere_f32(const float* p0, int32_t n0, const float* p1, int32_t n1, int32_t ld, float* out0, float* out1, float* inverse,
+                                int32_t B, void* stream) {
+    FC_API_BEGIN
+    if (!p0 || !out0 || !inverse || (n1 > 0 && (!p1 || !out1))) throw fc::Error(FC_ERR_INVALID, "fc_stage_co_unit_sphere_f32: null pointer");
+    fc::launch_co_unit_sphere(p0, n0, n1 > 0 ? p1 : p0, n1, ld, out0, n1 > 0 ? out1 : out0, inverse, B, (hipStream_t)stream);
+    FC_API_END
+}
+
+int fc_clamp_infs_f32(float* t, int64_t n, void* stream) {
+    FC_API_BEGIN
+    if (!t || n < 0) throw fc::Error(FC_ERR_INVALID, "fc_clamp_infs_f32: bad argument");
+    fc::TmpBuf tmp(4 * sizeof(float) + sizeof(int));
+    fc::launch_clamp_infs(t, (long)n, tmp.f(), (int*)(tmp.f() + 4), (hipStream_t)stream);
+    FC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    FC_API_END
+}
+
+int fc_change_map_f32(float* lp10, int32_t N, float* lp00, int32_t N0, float* out, int32_t B, float multiple, float hard_cutoff,
+                      int32_t use_cutoff, int32_t* invalid, void* stream) {
+    FC_API_BEGIN
+    if (!lp10 || !lp00 || !out || !invalid) throw fc::Error(FC_ERR_INVALID, "fc_change_map_f32: null pointer");
+    fc::TmpBuf tmp(4 * sizeof(float) + sizeof(int));
+    int* status = (int*)(tmp.f() + 4);
+    fc::launch_change_map(lp10, N, lp00, N0, out, B, multiple, hard_cutoff, use_cutoff, tmp.f(), status, (hipStream_t)stream);
+    int h = 0;
+    FC_HIP(hipMemcpyAsync(&h, status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    FC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *invalid = h;
+    FC_API_END
+}
+
 int fc_op_rqspline_f32(const float* x, const float* params, float* y, float* logabsdet, int64_t n, int32_t K, int32_t inverse, void* stream) {
     FC_API_BEGIN
     if (!x || !params || !y || !logabsdet || n < 0) throw fc::Error(FC_ERR_INVALID, "fc_op_rqspline_f32: bad argument");

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FCFLOW_LIB", os.path.join(_HERE, "libfcflow.so"))   # FCFLOW_LIB: A/B another build in profiles/kernel_bench.py
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FLOW_TYPES = {"AffineCoupling": 0, "RationalQuadraticSplineCoupling": 1, "ExponentialCoupling": 2}
 SCALE_FNS = {"exp": 0, "sigmoid": 1}
@@ -27,6 +27,7 @@ EXPORTS = [
     "fc_paconv_create", "fc_paconv_destroy", "fc_paconv_out_dim", "fc_paconv_workspace_bytes", "fc_paconv_embed_f32", "fc_op_fps_f32",
     "fc_profile_enable", "fc_profile_reset", "fc_profile_report",
     "fc_op_linear_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
+    "fc_stage_fps_f32", "fc_stage_co_unit_sphere_f32", "fc_clamp_infs_f32", "fc_change_map_f32",
 ]
 
 
@@ -311,6 +312,55 @@ def op_fps(xyz, m):
     with torch.cuda.device(xyz.device):
         _check(lib().fc_op_fps_f32(_ptr(xyz), _ptr(idx), B, n, m, _stream()))
     return idx
+
+
+def stage_fps(pts, m, n_coord=None):
+    """pts [B,n,C] -> idx [B,m] int64 (fc_stage_fps_f32: torch_cluster.fps semantics, random_start=False)."""
+    pts = _dev_f32(pts)
+    B, n, ld = pts.shape
+    idx = torch.empty(B, m, dtype=torch.int64, device=pts.device)
+    with torch.cuda.device(pts.device):
+        _check(lib().fc_stage_fps_f32(_ptr(pts), ld, ld if n_coord is None else n_coord, _ptr(idx), B, n, m, _stream()))
+    return idx
+
+
+def stage_co_unit_sphere(p0, p1):
+    """p0 [B,n0,C], p1 [B,n1,C] -> (out0, out1, inverse [B,4] = furthest distance, mean xyz) (fc_stage_co_unit_sphere_f32)."""
+    p0, p1 = _dev_f32(p0), _dev_f32(p1)
+    B, n0, ld = p0.shape
+    if p1.shape[0] != B or p1.shape[2] != ld:
+        raise RuntimeError(f"co_unit_sphere: clouds of shape {tuple(p0.shape)} and {tuple(p1.shape)} do not pair up")
+    o0, o1 = torch.empty_like(p0), torch.empty_like(p1)
+    inv = torch.empty(B, 4, dtype=torch.float32, device=p0.device)
+    with torch.cuda.device(p0.device):
+        _check(lib().fc_stage_co_unit_sphere_f32(_ptr(p0), n0, _ptr(p1), p1.shape[1], ld, _ptr(o0), _ptr(o1), _ptr(inv), B, _stream()))
+    return o0, o1, inv
+
+
+def clamp_infs(t):
+    """fc_clamp_infs_f32 in place on a contiguous fp32 device tensor."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError("clamp_infs: expects a contiguous float32 tensor on the GPU (flowcompare_amd has no CPU fallback)")
+    with torch.cuda.device(t.device):
+        _check(lib().fc_clamp_infs_f32(_ptr(t), ctypes.c_int64(t.numel()), _stream()))
+    return t
+
+
+def change_map(lp10, lp00, multiple, hard_cutoff=None):
+    """fc_change_map_f32 on contiguous fp32 [B,N] / [B,N0] device tensors (clamped in place); returns (out, invalid flag)."""
+    for t in (lp10, lp00):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 2):
+            raise RuntimeError("change_map: expects contiguous float32 [B, N] tensors on the GPU (flowcompare_amd has no CPU fallback)")
+    B, N = lp10.shape
+    if lp00.shape[0] != B:
+        raise RuntimeError("change_map: batch sizes differ")
+    out = torch.empty_like(lp10)
+    bad = ctypes.c_int32(0)
+    with torch.cuda.device(lp10.device):
+        _check(lib().fc_change_map_f32(_ptr(lp10), N, _ptr(lp00), lp00.shape[1], _ptr(out), B, ctypes.c_float(multiple),
+                                       ctypes.c_float(0.0 if hard_cutoff is None else hard_cutoff), 0 if hard_cutoff is None else 1,
+                                       ctypes.byref(bad), _stream()))
+    return out, bool(bad.value)
 
 
 def op_linear(x, W, bias=None, residual=None, act="none"):

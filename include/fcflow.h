@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 1
+#define FC_ABI_VERSION 2
 
 enum fc_status {
     FC_OK = 0,
@@ -137,6 +137,25 @@ int fc_paconv_embed_f32(fc_paconv* emb, const float* pts, float* out, int32_t B,
 /* furthest point sampling alone (lib/pointops/src/sampling/sampling_cuda_kernel.cu:58-168): xyz [B,n,3] -> idx [B,m] int32.
  * Also the FPS subsampling step of the data loader that feeds the path. */
 int fc_op_fps_f32(const float* xyz, int32_t* idx, int32_t B, int32_t n, int32_t m, void* stream);
+
+/* ---- the steps either side of the path ------------------------ */
+/* Farthest point subsampling of the voxel loader (dataloaders/ams_voxel_loader.py:298-307: torch_cluster.fps(x, batch=0,
+ * ratio, random_start=False) on the FULL feature rows).  pts [B, n, ld] (first C <= 8 columns are the coordinates) ->
+ * idx [B, m] int64 in selection order, idx[:,0] = 0, ties to the lowest index. */
+int fc_stage_fps_f32(const float* pts, int32_t ld, int32_t C, int64_t* idx, int32_t B, int32_t n, int32_t m, void* stream);
+/* Joint unit-sphere normalisation (utils.py:259-280 co_unit_sphere / unit_sphere): over cat(p0[b], p1[b]) subtract the xyz
+ * mean, divide by the largest xyz norm; other columns pass through.  p0 [B,n0,ld], p1 [B,n1,ld] -> out0, out1;
+ * inverse [B,4] = furthest_distance, mean x, y, z (the dict the reference returns with return_inverse=True). */
+int fc_stage_co_unit_sphere_f32(const float* p0, int32_t n0, const float* p1, int32_t n1, int32_t ld, float* out0, float* out1,
+                                float* inverse, int32_t B, void* stream);
+/* Change map (test_flow.py:241-275 log_prob_to_change + clamp_infs): lp10 [B,N], lp00 [B,N0] are clamped IN PLACE when they
+ * hold infs (all infs of a tensor -> its smallest non-inf entry), out [B,N] = 1 - (lp10 - min)/(max - min) where
+ * lp10 < mean(lp00) - multiple * std(lp00) (per scene, unbiased std) or, with use_cutoff, lp10 < hard_cutoff; 0 elsewhere.
+ * *invalid (host) is set to 1 when the result holds NaN / inf (the reference asserts is_valid). Synchronises the stream. */
+/* clamp_infs alone (test_flow.py:241-247): every +-inf of t[0..n) becomes the smallest non-inf entry, in place. */
+int fc_clamp_infs_f32(float* t, int64_t n, void* stream);
+int fc_change_map_f32(float* lp10, int32_t N, float* lp00, int32_t N0, float* out, int32_t B, float multiple, float hard_cutoff,
+                      int32_t use_cutoff, int32_t* invalid, void* stream);
 
 /* ---- in-library kernel timing (used by bench.py for the roofline object) --------------------- */
 /* When enabled, every kernel launch of this library is bracketed by HIP events on its launch stream.
