@@ -102,7 +102,7 @@ inline int gemm_n_alloc(int N_pad) {
 // A operand segment: rows x seg_k floats starting at ptr with row pitch lda
 struct ASeg { const float* ptr; int lda; };
 
-enum Epilogue { EPI_LINEAR = 0, EPI_AFFINE = 1, EPI_AUGMENT = 2, EPI_SLICE = 3 };
+enum Epilogue { EPI_LINEAR = 0, EPI_AFFINE = 1, EPI_AUGMENT = 2, EPI_SLICE = 3, EPI_SPLINE = 4 };
 
 struct GemmEpi {
     // EPI_LINEAR
@@ -125,6 +125,11 @@ struct GemmEpi {
     const float* val = nullptr; int ldval = 0;             // SLICE: values whose log N(.; mu, sigma) is ADDED to logprob
     const float* val_shift = nullptr; const float* val_scale = nullptr;   // SLICE: v = (val - shift) * scale ; AUGMENT(+inverse): z = z / scale + shift
     int rows_valid = 0;        // rows that exist in user-visible outputs
+    // EPI_SPLINE (forward rational-quadratic spline coupling evaluated by the workgroup that produced the parameters; uses
+    // xbuf / ldx / x2_col0 / d2 / rows_valid above): y2 overwrites x2, per-tile log-det partials go to ldj_part[tile * ldj_pitch + row]
+    int spline_K = 0;
+    float* ldj_part = nullptr;
+    size_t ldj_pitch = 0;
     double flops_hint = 0.0;   // filled by launch_gemm for the profiler
 };
 
@@ -139,6 +144,7 @@ struct Fp16Guard {
     int* flag; hipStream_t stream; bool open;
 };
 bool gemm_fp16_enabled();
+bool gemm_split_enabled();        // a split (limb) GEMM loop is the active variant: the fused spline epilogue is available
 int* gemm_fp16_flag();         // the open scope's device flag of the calling thread, or null
 template <class F>
 inline void run_fp16_guarded(int* dev_flag, hipStream_t s, F&& fn) {
@@ -170,8 +176,9 @@ void launch_attention_op(const float* q, const float* k, const float* v, float* 
                          void* limb_ws, hipStream_t s);
 void launch_base_density(const float* x, int ldx, int d1, int d1_pad, int d2, float* logprob, float log_const,
                          float* z_out, int D, int rows, hipStream_t s);
-void launch_spline(const float* params, int ldp, int d2s, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows,
-                   int inverse, hipStream_t s);   // params[row, p*d2s + j] = parameter p of dim j
+void launch_spline(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows, int inverse,
+                   hipStream_t s);       // parameters in the tile-grouped dim-major layout of spline.h
+void launch_ldj_reduce(const float* part, int ntiles, size_t pitch, float* logprob, int rows, hipStream_t s);   // params[row, p*d2s + j] = parameter p of dim j
 void launch_expm_coupling(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, const float* scal4, float* logprob,
                           int rows, int inverse, hipStream_t s);
 void launch_spline_flat(const float* x, const float* params, float* y, float* lad, int64_t n, int K, int inverse, hipStream_t s);

@@ -16,6 +16,7 @@
 #include <cstring>
 
 #include "hostpack.h"
+#include "spline.h"
 
 namespace fc {
 
@@ -251,12 +252,12 @@ static void build_out_layer(fc_flow& f, const WeightTable& wt, const std::string
         const int per = 3 * f.cfg.num_bins_spline + 1;
         if (n != per * d.d1) throw Error(FC_ERR_SHAPE, prefix + ".out_layer: spline coupling expects (3K+1)*(D/2) outputs");
         if (n != per * d.d2) throw Error(FC_ERR_UNSUPPORTED, "spline coupling with odd latent_dim fails in the reference too (reshape)");
-        // parameter-major output: column p*d2s + j holds parameter p of transformed dim j (reference order is j*(3K+1) + p), so the
-        // spline kernel's lane j reads every parameter with a coalesced row access and needs no LDS transpose
-        const int d2s = round_up(d.d2, 8);
-        nmap.assign(round_up(per * d2s, 32), -1);
-        for (int pp = 0; pp < per; ++pp)
-            for (int j = 0; j < d.d2; ++j) nmap[pp * d2s + j] = j * per + pp;
+        // tile-grouped dim-major output (spline.h): a 128-column GEMM tile holds all 3K+1 parameters of DPT transformed dims, so the
+        // workgroup that produced the tile evaluates those splines in its epilogue (reference order is j*(3K+1) + p)
+        const int K = f.cfg.num_bins_spline;
+        nmap.assign(spline_ncols(d.d2, K), -1);
+        for (int j = 0; j < d.d2; ++j)
+            for (int pp = 0; pp < per; ++pp) nmap[spline_col(j, pp, K)] = j * per + pp;
     } else {
         if (n != d.d2 * d.d2 + d.d2) throw Error(FC_ERR_SHAPE, prefix + ".out_layer: exponential coupling expects d2^2 + d2 outputs");
         nmap = map_prefix(n, round_up(n, 32));
@@ -422,6 +423,7 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
 struct FlowWs {
     float *xa, *xb, *h[3], *q, *a, *ctxp, *kv, *xin, *rowscal, *spl, *cbuf;
     void* kv16;      // K / V limb images of the layer in flight (split-fp16 attention)
+    float* ldjp;     // per-column-tile log-det partials of the fused spline epilogue, [tiles][P_pad]
     int P, P_pad, Pc, Pc_pad, ldkv;
 };
 static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t bytes, bool dry, size_t* need) {
@@ -442,6 +444,7 @@ static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t by
     w.rowscal = c.floats((size_t)w.P_pad);
     w.spl = c.floats(d.ldp ? (size_t)w.P_pad * d.ldp : 1);
     w.cbuf = c.floats(d.nz > 0 ? (size_t)w.P_pad * d.nz_pad : 1);
+    w.ldjp = c.floats(f.cfg.flow_type == FC_FLOW_SPLINE ? (size_t)(d.ldp / 128) * w.P_pad : 1);
     w.kv16 = c.bytes(f.n_attn > 0 ? std::max<size_t>(attention_limb_ws_bytes(w.Pc_pad, d.I_pad), 16) : 16);
     if (need) *need = c.off + 256;
     return w;
@@ -493,12 +496,19 @@ static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, c
         e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = d.d1_pad; e.d2 = d.d2; e.scale_fn = c.affine_scale_fn;
         e.logprob = logprob; e.rows_valid = w.P; e.inverse = inverse;
         launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_AFFINE, s);
+    } else if (c.flow_type == FC_FLOW_SPLINE && !inverse && gemm_split_enabled() && b.net.out_layer.W3 != nullptr) {
+        // forward: the parameter GEMM evaluates the splines in its epilogue; only per-tile log-det partials leave the kernel
+        GemmEpi e{};
+        e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = d.d1_pad; e.d2 = d.d2; e.spline_K = c.num_bins_spline; e.rows_valid = w.P;
+        e.ldj_part = w.ldjp; e.ldj_pitch = (size_t)w.P_pad;
+        launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_SPLINE, s);
+        launch_ldj_reduce(w.ldjp, b.net.out_layer.N_pad / 128, (size_t)w.P_pad, logprob, w.P, s);
     } else {
         GemmEpi e{};
         e.C = w.spl; e.ldc = d.ldp; e.rows_valid = w.P;
         launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_LINEAR, s);
         if (c.flow_type == FC_FLOW_SPLINE)
-            launch_spline(w.spl, d.ldp, round_up(d.d2, 8), xc, d.ldx, d.d1_pad, d.d2, c.num_bins_spline, logprob, w.P, inverse, s);
+            launch_spline(w.spl, d.ldp, xc, d.ldx, d.d1_pad, d.d2, c.num_bins_spline, logprob, w.P, inverse, s);
         else
             launch_expm_coupling(w.spl, d.ldp, xc, d.ldx, d.d1_pad, d.d2, b.expm_scal, logprob, w.P, inverse, s);
     }

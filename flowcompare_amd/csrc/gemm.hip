@@ -14,6 +14,7 @@
 // Global -> LDS goes through registers (prefetch of tile t+1 is issued before the MFMAs of tile t, written
 // after them): one barrier per 32-deep K tile.
 #include "common.h"
+#include "spline.h"
 #include <atomic>
 #include <cstdio>
 
@@ -152,7 +153,7 @@ void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         float bv = 0.f;
-        if constexpr (EPI == EPI_LINEAR) bv = p.bias ? p.bias[wave_n0 + j * 32 + li] : 0.f;
+        if constexpr (EPI == EPI_LINEAR || EPI == EPI_SPLINE) bv = p.bias ? p.bias[wave_n0 + j * 32 + li] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -458,6 +459,42 @@ void gemm_f32_kernel(const GemmParams p) {
                 }
             }
         }
+    } else if constexpr (EPI == EPI_SPLINE) {
+        // ---- fused rational-quadratic spline coupling (forward).  The parameter layer's columns are laid out so that this
+        //      128-column tile holds all 3K+1 parameters of DPT transformed dims (spline.h): the tile goes through LDS (the
+        //      accumulator layout has one parameter per lane), then each thread evaluates whole splines.  Nothing of the
+        //      [rows, 25*d2] parameter matrix is written to or re-read from HBM.
+        static_assert(BN == 128, "spline epilogue: the column layout is built for 128-column tiles");
+        constexpr int TP = BN + 1;                                   // odd pitch: lanes walk rows conflict-free
+        float* tile = smem;                                          // aliases the staging buffers (all reads are behind the loop's last barrier)
+        float* part = smem + BM * TP;                                // [DPT][BM] log-det terms
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tile[(wr * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TP + wc * TN * 32 + j * 32 + li] = acc[i][j][r];
+        __syncthreads();
+        const int K = e.spline_K, per = 3 * K + 1, DPT = BN / per;
+        const int dim0 = bn * DPT;
+        for (int it = tid; it < BM * DPT; it += NT) {
+            const int row = it % BM, dl = it / BM;
+            float lad = 0.f;
+            if (dim0 + dl < e.d2 && m0 + row < e.rows_valid) {
+                float* xp = e.xbuf + (size_t)(m0 + row) * e.ldx + e.x2_col0 + dim0 + dl;
+                float y;
+                rq_any(K, *xp, tile + row * TP + dl * per, 1, false, y, lad);
+                *xp = y;
+            }
+            part[dl * BM + row] = lad;
+        }
+        __syncthreads();
+        if (tid < BM) {
+            float sum = 0.f;
+            for (int dl = 0; dl < DPT; ++dl) sum += part[dl * BM + tid];
+            e.ldj_part[(size_t)bn * e.ldj_pitch + m0 + tid] = sum;
+        }
     } else {
         static_assert(EPI == EPI_LINEAR || (TN % 2 == 0), "pair-packed epilogues need an even number of column tiles");
         float lsum[TM][16];
@@ -530,12 +567,13 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 5, g_gemm_stagger = 0, g_gemm_colgroup = 10, g_gemm_bigtile = 1, g_gemm_k32 = 0;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 5, g_gemm_stagger = 0, g_gemm_colgroup = 10, g_gemm_bigtile = 1, g_gemm_k32 = 0, g_fused_spline = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
 
 bool gemm_fp16_enabled() { return g_gemm_variant == 5; }
+bool gemm_split_enabled() { return (g_gemm_variant == 5 || g_gemm_variant == 3) && g_fused_spline; }
 int* gemm_fp16_flag() { return g_gemm_variant == 5 ? t_fp16_flag : nullptr; }
 long gemm_fp16_fallbacks() { return g_fp16_fallbacks.load(); }
 Fp16Guard::Fp16Guard(int* dev_flag, hipStream_t s) : flag(dev_flag), stream(s), open(true) {
@@ -555,8 +593,10 @@ bool Fp16Guard::overflowed() {
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds = VAR == 6 ? 2 * (size_t)(BM + BN) * 144 : VAR == 5 ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds_main = VAR == 6 ? 2 * (size_t)(BM + BN) * 144 : VAR == 5 ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
+    constexpr size_t lds_epi = EPI == EPI_SPLINE ? ((size_t)BM * (BN + 1) + (size_t)BM * 9) * sizeof(float) : 0;   // tile + <= 9 dims of log-dets
+    constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, EPI, VAR>;
     if (!attr_done) {
         FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -588,7 +628,7 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         kt += p.kt[i];
     }
     if (kt * 32 != L.K_pad) throw Error(FC_ERR_INVALID, "launch_gemm: segment widths do not add up to K_pad");
-    if (L.n_alloc < round_up(L.N_pad, gemm_bn(L.N_pad, epi_kind != EPI_LINEAR)) || L.n_alloc < round_up(L.N_pad, 128))
+    if (L.n_alloc < round_up(L.N_pad, gemm_bn(L.N_pad, epi_kind != EPI_LINEAR && epi_kind != EPI_SPLINE)) || L.n_alloc < round_up(L.N_pad, 128))
         throw Error(FC_ERR_INVALID, "launch_gemm: W is not zero-padded to the column-tile grid (PackedLinear.n_alloc)");
     p.KT = kt;
     GemmEpi e = e_in;
@@ -626,6 +666,13 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             p.nbm = rows_alloc / 128;
             if (split) launch_cfg<128, 320, 4, 1, EPI_LINEAR, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_LINEAR>(p, s);
         }
+    } else if (epi_kind == EPI_SPLINE) {
+        const int K = e.spline_K;
+        if (!split) throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: the fused spline epilogue exists for the split GEMM loops only");
+        if ((K != 4 && K != 8 && K != 16) || L.N_pad != spline_ncols(e.d2, K) || !e.xbuf || !e.ldj_part || e.ldj_pitch < (size_t)rows_alloc)
+            throw Error(FC_ERR_INVALID, "launch_gemm: bad fused-spline arguments (layout of spline.h, per-tile log-det buffer)");
+        p.nbm = rows_alloc / 128;
+        if (f16) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 5>(p, s); else launch_cfg<128, 128, 2, 2, EPI_SPLINE, 3>(p, s);
     } else {
         if (!L.bias || L.N_pad % 64 != 0) throw Error(FC_ERR_INVALID, "launch_gemm: pair-packed epilogue needs bias and N_pad % 64 == 0");
         p.nbm = rows_alloc / 128;

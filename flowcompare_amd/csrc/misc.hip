@@ -2,6 +2,7 @@
 // rational-quadratic spline, DGCNN gather-max and global pooling.  All are one-wave-per-row streaming
 // kernels (coalesced row reads, wave reductions via DPP shuffles); none of them is reshaped into a GEMM.
 #include "common.h"
+#include "spline.h"
 
 namespace fc {
 
@@ -117,116 +118,10 @@ void launch_base_density(const float* x, int ldx, int d1, int d1_pad, int d2, fl
     FC_HIP(hipGetLastError());
 }
 
-// ---------------------------------------------------------------- rational-quadratic spline
-// One element: models/spline_coupling.py:24-66 (tails) + :69-169 (spline) + :17-19 (searchsorted).
-// u points at 3K+1 parameters [K widths | K heights | K+1 derivative logits] with element stride `us`.
-// Quirks reproduced: derivative logits are padded left with log(exp(1-min_d-1)); knot i>=1 uses ud[i-1];
-// ud[K] is never used; last knot + 1e-6 only for the bin search; outside [-3,3] identity with logabsdet 0.
-// v_exp_f32 / v_log_f32 / v_rcp_f32 based helpers (about 1 ulp on the base-2 function): the spline evaluates 16 exponentials,
-// 2 softplus, 2 logs and ~10 divisions per element, which made the ocml versions the kernel's dominant VALU cost.
-__device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
-__device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.6931471805599453f; }
-__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-
-template <int K>
-__device__ __forceinline__ void rq_spline_elem(float x, const float* u, int us, bool inverse, float& y, float& lad) {
-    constexpr float B = 3.0f, MINW = 1e-3f, MINH = 1e-3f, MIND = 1e-3f;
-    if (!(x >= -B && x <= B)) { y = x; lad = 0.f; return; }
-    float cw[K + 1], ch[K + 1];
-    {
-        float e[K], mx = u[0];
-#pragma unroll
-        for (int i = 0; i < K; ++i) { e[i] = u[i * us]; mx = fmaxf(mx, e[i]); }
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < K; ++i) { e[i] = fast_exp(e[i] - mx); sum += e[i]; }
-        float c = 0.f;
-        const float rs = __builtin_amdgcn_rcpf(sum);
-        cw[0] = -B;
-#pragma unroll
-        for (int i = 0; i < K; ++i) { c += MINW + (1.0f - MINW * K) * (e[i] * rs); cw[i + 1] = 2.0f * B * c - B; }
-        cw[K] = B;
-    }
-    {
-        float e[K], mx = u[K * us];
-#pragma unroll
-        for (int i = 0; i < K; ++i) { e[i] = u[(K + i) * us]; mx = fmaxf(mx, e[i]); }
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < K; ++i) { e[i] = fast_exp(e[i] - mx); sum += e[i]; }
-        float c = 0.f;
-        const float rs = __builtin_amdgcn_rcpf(sum);
-        ch[0] = -B;
-#pragma unroll
-        for (int i = 0; i < K; ++i) { c += MINH + (1.0f - MINH * K) * (e[i] * rs); ch[i + 1] = 2.0f * B * c - B; }
-        ch[K] = B;
-    }
-    // bin = #{knots <= x} - 1 over the searched knots (last one + 1e-6)
-    int bin = 0;
-#pragma unroll
-    for (int i = 1; i <= K; ++i) {
-        const float knot = (inverse ? ch[i] : cw[i]) + (i == K ? 1e-6f : 0.f);
-        bin += (x >= knot) ? 1 : 0;
-    }
-    float in_cw = cw[0], in_w = cw[1] - cw[0], in_ch = ch[0], in_h = ch[1] - ch[0];
-    float ud0 = 0.f, ud1 = u[(2 * K) * us];
-#pragma unroll
-    for (int i = 1; i < K; ++i) {
-        if (bin == i) {
-            in_cw = cw[i]; in_w = cw[i + 1] - cw[i]; in_ch = ch[i]; in_h = ch[i + 1] - ch[i];
-            ud0 = u[(2 * K + i - 1) * us]; ud1 = u[(2 * K + i) * us];
-        }
-    }
-    const float cst = -1e-3f;                                   // log(exp(1 - min_derivative - 1))
-    const float raw0 = bin == 0 ? cst : ud0;
-    auto softplus = [](float v) { return v > 20.f ? v : fast_log(1.0f + fast_exp(v)); };
-    const float d0 = MIND + softplus(raw0), d1 = MIND + softplus(ud1);
-    const float rw = __builtin_amdgcn_rcpf(in_w);
-    const float delta = in_h * rw;
-    if (!inverse) {
-        const float th = (x - in_cw) * rw;
-        const float tt = th * (1.0f - th);
-        const float num = in_h * (delta * th * th + d0 * tt);
-        const float den = delta + (d0 + d1 - 2.0f * delta) * tt;
-        y = in_ch + fast_div(num, den);
-        const float omt = 1.0f - th;
-        const float dnum = delta * delta * (d1 * th * th + 2.0f * delta * tt + d0 * omt * omt);
-        lad = fast_log(dnum) - 2.0f * fast_log(den);
-    } else {
-        const float dy = x - in_ch;
-        const float t3 = d0 + d1 - 2.0f * delta;
-        const float qa = dy * t3 + in_h * (delta - d0);
-        const float qb = in_h * d0 - dy * t3;
-        const float qc = -delta * dy;
-        const float disc = qb * qb - 4.0f * qa * qc;
-        const float root = fast_div(2.0f * qc, -qb - sqrtf(disc));
-        y = root * in_w + in_cw;
-        const float tt = root * (1.0f - root);
-        const float den = delta + t3 * tt;
-        const float omr = 1.0f - root;
-        const float dnum = delta * delta * (d1 * root * root + 2.0f * delta * tt + d0 * omr * omr);
-        lad = -(fast_log(dnum) - 2.0f * fast_log(den));
-    }
-}
-
-template <int K>
-__device__ __forceinline__ void rq_dispatch(float x, const float* u, int us, bool inv, float& y, float& lad) {
-    rq_spline_elem<K>(x, u, us, inv, y, lad);
-}
-
-__device__ __forceinline__ void rq_any(int K, float x, const float* u, int us, bool inv, float& y, float& lad) {
-    switch (K) {
-        case 4: rq_dispatch<4>(x, u, us, inv, y, lad); break;
-        case 8: rq_dispatch<8>(x, u, us, inv, y, lad); break;
-        case 16: rq_dispatch<16>(x, u, us, inv, y, lad); break;
-        default: y = x; lad = 0.f; break;     // rejected on the host
-    }
-}
-
-// One wave per point row; lane j handles dims j, j+64, ...  The producing GEMM emits the parameters PARAMETER-major
-// (params[row, p*d2s + j]), so every parameter read is a coalesced row access (element stride d2s inside rq_spline_elem).
-// y2 overwrites x2 in place; forward adds the row's sum of logabsdet to logprob.
-__global__ __launch_bounds__(256) void spline_rows_kernel(const float* __restrict__ params, int ldp, int d2s, float* xbuf, int ldx, int x2_col0,
+// One wave per point row; lane j handles dims j, j+64, ...  Parameters arrive in the tile-grouped dim-major layout of spline.h
+// (the producing GEMM normally evaluates the spline in its own epilogue; this kernel serves the inverse direction and the
+// non-split GEMM variants).  y2 overwrites x2 in place; forward adds the row's sum of logabsdet to logprob.
+__global__ __launch_bounds__(256) void spline_rows_kernel(const float* __restrict__ params, int ldp, float* xbuf, int ldx, int x2_col0,
                                                           int d2, int K, float* logprob, int rows, int inverse) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
@@ -236,21 +131,33 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const float* __restric
     float* xr = xbuf + (size_t)row * ldx + x2_col0;
     for (int j = lane; j < d2; j += 64) {
         float y, lad;
-        rq_any(K, xr[j], pr + j, d2s, inverse != 0, y, lad);
+        rq_any(K, xr[j], pr + spline_col(j, 0, K), 1, inverse != 0, y, lad);
         xr[j] = y;
         acc += lad;
     }
     acc = wave_sum(acc);
     if (lane == 0 && !inverse) logprob[row] += acc;
 }
-void launch_spline(const float* params, int ldp, int d2s, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows, int inverse,
+void launch_spline(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, int K, float* logprob, int rows, int inverse,
                    hipStream_t s) {
     if (K != 4 && K != 8 && K != 16) throw Error(FC_ERR_UNSUPPORTED, "spline: num_bins_spline must be 4, 8 or 16");
-    const int npar = (3 * K + 1) * d2s;
-    if (ldp < npar || d2s < d2) throw Error(FC_ERR_INVALID, "spline: parameter pitch too small");
-    ProfScope ps("fc::spline_rows_kernel(float const*, int, int, float*, int, int, int, int, float*, int, int)", 0.0,
-                 4.0 * rows * ((3.0 * K + 1) * d2 + 2.0 * d2 + 2.0), s);
-    hipLaunchKernelGGL(spline_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, params, ldp, d2s, xbuf, ldx, x2_col0, d2, K, logprob, rows, inverse);
+    if (ldp < spline_ncols(d2, K)) throw Error(FC_ERR_INVALID, "spline: parameter pitch too small");
+    ProfScope ps("fc::spline_rows_kernel", 0.0, 4.0 * rows * ((3.0 * K + 1) * d2 + 2.0 * d2 + 2.0), s);
+    hipLaunchKernelGGL(spline_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, params, ldp, xbuf, ldx, x2_col0, d2, K, logprob, rows, inverse);
+    FC_HIP(hipGetLastError());
+}
+
+// logprob[row] += sum over the column tiles of the fused spline epilogue's per-tile log-det partials (fixed order: reproducible)
+__global__ __launch_bounds__(256) void ldj_reduce_kernel(const float* __restrict__ part, int ntiles, size_t pitch, float* __restrict__ logprob, int rows) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int t = 0; t < ntiles; ++t) s += part[(size_t)t * pitch + row];
+    logprob[row] += s;
+}
+void launch_ldj_reduce(const float* part, int ntiles, size_t pitch, float* logprob, int rows, hipStream_t s) {
+    ProfScope ps("fc::ldj_reduce_kernel", 0.0, 4.0 * rows * (ntiles + 2.0), s);
+    hipLaunchKernelGGL(ldj_reduce_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, ntiles, pitch, logprob, rows);
     FC_HIP(hipGetLastError());
 }
 

@@ -23,7 +23,7 @@ struct TmpBuf {
     return FC_OK;
 
 namespace fc { long gemm_fp16_fallbacks(); }
-namespace fc { extern int g_gemm_variant, g_gemm_stagger, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_gemm_k32; }
+namespace fc { extern int g_gemm_variant, g_gemm_stagger, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_gemm_k32, g_fused_spline; }
 
 extern "C" {
 
@@ -35,6 +35,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 3) fc::g_gemm_bigtile = value;
     else if (key == 5) fc::g_attn_fp16 = value;
     else if (key == 6) fc::g_gemm_k32 = value;
+    else if (key == 7) fc::g_fused_spline = value;
     else return FC_ERR_INVALID;
     return FC_OK;
 }

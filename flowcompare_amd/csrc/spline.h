@@ -1,0 +1,122 @@
+// Rational-quadratic spline element (shared by the stand-alone spline kernels in misc.hip and the fused GEMM epilogue in gemm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fc {
+
+// ---------------------------------------------------------------- rational-quadratic spline
+// One element: models/spline_coupling.py:24-66 (tails) + :69-169 (spline) + :17-19 (searchsorted).
+// u points at 3K+1 parameters [K widths | K heights | K+1 derivative logits] with element stride `us`.
+// Quirks reproduced: derivative logits are padded left with log(exp(1-min_d-1)); knot i>=1 uses ud[i-1];
+// ud[K] is never used; last knot + 1e-6 only for the bin search; outside [-3,3] identity with logabsdet 0.
+// v_exp_f32 / v_log_f32 / v_rcp_f32 based helpers (about 1 ulp on the base-2 function): the spline evaluates 16 exponentials,
+// 2 softplus, 2 logs and ~10 divisions per element, which made the ocml versions the kernel's dominant VALU cost.
+__device__ __forceinline__ float fast_exp(float v) { return __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float v) { return __builtin_amdgcn_logf(v) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
+template <int K>
+__device__ __forceinline__ void rq_spline_elem(float x, const float* u, int us, bool inverse, float& y, float& lad) {
+    constexpr float B = 3.0f, MINW = 1e-3f, MINH = 1e-3f, MIND = 1e-3f;
+    if (!(x >= -B && x <= B)) { y = x; lad = 0.f; return; }
+    float cw[K + 1], ch[K + 1];
+    {
+        float e[K], mx = u[0];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { e[i] = u[i * us]; mx = fmaxf(mx, e[i]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { e[i] = fast_exp(e[i] - mx); sum += e[i]; }
+        float c = 0.f;
+        const float rs = __builtin_amdgcn_rcpf(sum);
+        cw[0] = -B;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { c += MINW + (1.0f - MINW * K) * (e[i] * rs); cw[i + 1] = 2.0f * B * c - B; }
+        cw[K] = B;
+    }
+    {
+        float e[K], mx = u[K * us];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { e[i] = u[(K + i) * us]; mx = fmaxf(mx, e[i]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { e[i] = fast_exp(e[i] - mx); sum += e[i]; }
+        float c = 0.f;
+        const float rs = __builtin_amdgcn_rcpf(sum);
+        ch[0] = -B;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { c += MINH + (1.0f - MINH * K) * (e[i] * rs); ch[i + 1] = 2.0f * B * c - B; }
+        ch[K] = B;
+    }
+    // bin = #{knots <= x} - 1 over the searched knots (last one + 1e-6)
+    int bin = 0;
+#pragma unroll
+    for (int i = 1; i <= K; ++i) {
+        const float knot = (inverse ? ch[i] : cw[i]) + (i == K ? 1e-6f : 0.f);
+        bin += (x >= knot) ? 1 : 0;
+    }
+    float in_cw = cw[0], in_w = cw[1] - cw[0], in_ch = ch[0], in_h = ch[1] - ch[0];
+    float ud0 = 0.f, ud1 = u[(2 * K) * us];
+#pragma unroll
+    for (int i = 1; i < K; ++i) {
+        if (bin == i) {
+            in_cw = cw[i]; in_w = cw[i + 1] - cw[i]; in_ch = ch[i]; in_h = ch[i + 1] - ch[i];
+            ud0 = u[(2 * K + i - 1) * us]; ud1 = u[(2 * K + i) * us];
+        }
+    }
+    const float cst = -1e-3f;                                   // log(exp(1 - min_derivative - 1))
+    const float raw0 = bin == 0 ? cst : ud0;
+    auto softplus = [](float v) { return v > 20.f ? v : fast_log(1.0f + fast_exp(v)); };
+    const float d0 = MIND + softplus(raw0), d1 = MIND + softplus(ud1);
+    const float rw = __builtin_amdgcn_rcpf(in_w);
+    const float delta = in_h * rw;
+    if (!inverse) {
+        const float th = (x - in_cw) * rw;
+        const float tt = th * (1.0f - th);
+        const float num = in_h * (delta * th * th + d0 * tt);
+        const float den = delta + (d0 + d1 - 2.0f * delta) * tt;
+        y = in_ch + fast_div(num, den);
+        const float omt = 1.0f - th;
+        const float dnum = delta * delta * (d1 * th * th + 2.0f * delta * tt + d0 * omt * omt);
+        lad = fast_log(dnum) - 2.0f * fast_log(den);
+    } else {
+        const float dy = x - in_ch;
+        const float t3 = d0 + d1 - 2.0f * delta;
+        const float qa = dy * t3 + in_h * (delta - d0);
+        const float qb = in_h * d0 - dy * t3;
+        const float qc = -delta * dy;
+        const float disc = qb * qb - 4.0f * qa * qc;
+        const float root = fast_div(2.0f * qc, -qb - sqrtf(disc));
+        y = root * in_w + in_cw;
+        const float tt = root * (1.0f - root);
+        const float den = delta + t3 * tt;
+        const float omr = 1.0f - root;
+        const float dnum = delta * delta * (d1 * root * root + 2.0f * delta * tt + d0 * omr * omr);
+        lad = -(fast_log(dnum) - 2.0f * fast_log(den));
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void rq_dispatch(float x, const float* u, int us, bool inv, float& y, float& lad) {
+    rq_spline_elem<K>(x, u, us, inv, y, lad);
+}
+
+__device__ __forceinline__ void rq_any(int K, float x, const float* u, int us, bool inv, float& y, float& lad) {
+    switch (K) {
+        case 4: rq_dispatch<4>(x, u, us, inv, y, lad); break;
+        case 8: rq_dispatch<8>(x, u, us, inv, y, lad); break;
+        case 16: rq_dispatch<16>(x, u, us, inv, y, lad); break;
+        default: y = x; lad = 0.f; break;     // rejected on the host
+    }
+}
+
+// Column layout of the spline parameter layer's output ("tile-grouped, dim-major"): transformed dim j keeps its 3K+1 parameters
+// contiguous, and dims are grouped so that no group straddles a 128-column GEMM tile:
+//   column(j, p) = (j / DPT) * 128 + (j % DPT) * (3K+1) + p,   DPT = 128 / (3K+1)  (K = 8: 5 dims, 125 of 128 columns used)
+// so the workgroup that produced a 128x128 tile holds every parameter of DPT dims of its 128 rows and can evaluate the
+// splines in its epilogue.
+__host__ __device__ inline int spline_dpt(int K) { return 128 / (3 * K + 1); }
+__host__ __device__ inline int spline_col(int j, int pp, int K) { return (j / spline_dpt(K)) * 128 + (j % spline_dpt(K)) * (3 * K + 1) + pp; }
+__host__ __device__ inline int spline_ncols(int d2, int K) { return ((d2 + spline_dpt(K) - 1) / spline_dpt(K)) * 128; }
+
+}  // namespace fc
