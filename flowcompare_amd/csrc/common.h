@@ -126,7 +126,8 @@ struct GemmEpi {
     const float* val_shift = nullptr; const float* val_scale = nullptr;   // SLICE: v = (val - shift) * scale ; AUGMENT(+inverse): z = z / scale + shift
     int rows_valid = 0;        // rows that exist in user-visible outputs
     // EPI_SPLINE (forward rational-quadratic spline coupling evaluated by the workgroup that produced the parameters; uses
-    // xbuf / ldx / x2_col0 / d2 / rows_valid above): y2 overwrites x2, per-tile log-det partials go to ldj_part[tile * ldj_pitch + row]
+    // xbuf / ldx / x2_col0 / d2 / rows_valid above): y2 overwrites x2, per-tile log-dets are ACCUMULATED into ldj_part[tile * ldj_pitch + row]
+    // (the caller zeroes the buffer before the first layer and reduces it over the tiles once after the last, launch_ldj_reduce)
     int spline_K = 0;
     float* ldj_part = nullptr;
     size_t ldj_pitch = 0;

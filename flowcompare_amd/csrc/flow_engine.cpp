@@ -501,8 +501,7 @@ static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, c
         GemmEpi e{};
         e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = d.d1_pad; e.d2 = d.d2; e.spline_K = c.num_bins_spline; e.rows_valid = w.P;
         e.ldj_part = w.ldjp; e.ldj_pitch = (size_t)w.P_pad;
-        launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_SPLINE, s);
-        launch_ldj_reduce(w.ldjp, b.net.out_layer.N_pad / 128, (size_t)w.P_pad, logprob, w.P, s);
+        launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_SPLINE, s);       // log-dets accumulate in w.ldjp; flow_forward reduces them once
     } else {
         GemmEpi e{};
         e.C = w.spl; e.ldc = d.ldp; e.rows_valid = w.P;
@@ -574,6 +573,8 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
     int eps_i = 0;
 
     launch_fill(logprob, 0.f, (size_t)w.P, s);
+    const int ldj_tiles = c.flow_type == FC_FLOW_SPLINE ? d.ldp / 128 : 0;     // fused spline epilogues accumulate per-tile log-dets here
+    if (ldj_tiles) launch_fill(w.ldjp, 0.f, (size_t)ldj_tiles * w.P_pad, s);
     float* xc = w.xa;
     float* xn = w.xb;
     launch_fill(xc, 0.f, (size_t)w.P_pad * d.ldx, s);
@@ -615,6 +616,7 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
             std::swap(xc, xn);
         }
     }
+    if (ldj_tiles) launch_ldj_reduce(w.ldjp, ldj_tiles, (size_t)w.P_pad, logprob, w.P, s);
     launch_base_density(xc, d.ldx, d.d1, d.d1_pad, d.d2, logprob, (float)f.log_const, z_out, d.D, w.P, s);
 }
 

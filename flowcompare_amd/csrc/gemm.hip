@@ -493,7 +493,7 @@ void gemm_f32_kernel(const GemmParams p) {
         if (tid < BM) {
             float sum = 0.f;
             for (int dl = 0; dl < DPT; ++dl) sum += part[dl * BM + tid];
-            e.ldj_part[(size_t)bn * e.ldj_pitch + m0 + tid] = sum;
+            e.ldj_part[(size_t)bn * e.ldj_pitch + m0 + tid] += sum;      // this (tile, row) slot has one owner per launch: reproducible
         }
     } else {
         static_assert(EPI == EPI_LINEAR || (TN % 2 == 0), "pair-packed epilogues need an even number of column tiles");
