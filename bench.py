@@ -116,7 +116,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:             # under torch.distributed.run (also with one rank: exercises the RCCL path)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
