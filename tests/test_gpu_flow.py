@@ -158,3 +158,37 @@ def test_unsupported_and_bad_arguments_fail_loudly():
     with pytest.raises(RuntimeError, match="noise"):
         md["flow"].log_prob(fx.t("extract_1").to(DEV), context=torch.zeros(3, 24, 10, device=DEV),
                             extra_context=torch.zeros(3, 20, 1, device=DEV), eps=[])
+
+
+def test_out_of_fp16_range_activations_repeat_on_the_bf16_limb_path():
+    """Hidden activations of ~1e6 do not fit the fp16 limbs: the forward raises its range flag, is repeated with the bf16-limb
+    GEMMs, and still matches the reference golden.  A ReLU MLP is positively homogeneous, so scaling its
+    in_layer and every hidden bias by alpha and its out_layer weight by 1/alpha leaves the flow unchanged while every hidden
+    activation of that net grows by alpha."""
+    import ctypes
+    from flowcompare_amd import engine
+    lib = engine.lib()
+    lib.fc_debug_fp16_fallbacks.restype = ctypes.c_int64
+    fx = Fixture("e2e_tiny_spline_relu")
+    cfg = dict(fx.cfg)
+    sd_flow, sd_emb = fx.state_dicts()
+    batch = tuple(t.to(DEV) for t in (fx.t("extract_0"), fx.t("extract_1"), fx.t("extra")))
+    eps = [e.to(DEV) for e in fx.eps()]
+    ref = torch.from_numpy(fx.a["log_prob_f64"])
+    for alpha, expect_fallback in ((1.0, False), (1.0e6, True)):
+        sd = {k: v.clone() for k, v in sd_flow.items()}
+        pre = "transforms.4.transform.nn."
+        for k in sd:
+            if k.startswith(pre):
+                if k.startswith(pre + "in_layer.") or (k.startswith(pre + "layers.") and k.endswith(".bias")):
+                    sd[k] = sd[k] * alpha
+                elif k == pre + "out_layer.weight":
+                    sd[k] = sd[k] / alpha
+        md = fa.initialize_flow(cfg, device=DEV, mode="test")
+        fa.load_flow({"flow": sd, "input_embedder": sd_emb}, md)
+        before = lib.fc_debug_fp16_fallbacks()
+        _, lp, bpd = fa.inner_loop(batch, md, cfg, eps=eps)
+        assert (lib.fc_debug_fp16_fallbacks() > before) == expect_fallback
+        err = (lp.cpu().double() - ref).abs().max().item()
+        print(f"alpha {alpha:g}: fallback {expect_fallback}, max |log-prob - fp64 golden| {err:.2e}")
+        assert torch.isfinite(lp).all() and err < PER_POINT_TOL and abs(float(bpd) - float(fx.a["bpd_f64"])) < BPD_TOL
