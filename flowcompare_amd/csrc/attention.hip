@@ -126,13 +126,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[h2][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f(m_run - m_new);          // 0 on the first tile (m_run = -inf)
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // 0 on the first tile (m_run = -inf)
         float lt = 0.f;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[h2][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(s[h2][r] - m_new);   // raw v_exp_f32: arguments are <= 0, results below 2^-126 may flush to 0
                 s[h2][r] = pv;
                 lt += pv;
             }
@@ -353,13 +353,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[h2][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f(m_run - m_new);          // 0 on the first tile (m_run = -inf)
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // 0 on the first tile (m_run = -inf)
         float lt = 0.f;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[h2][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(s[h2][r] - m_new);   // raw v_exp_f32: arguments are <= 0, results below 2^-126 may flush to 0
                 s[h2][r] = pv;
                 lt += pv;
             }
