@@ -174,6 +174,7 @@ int fc_dgcnn_create(int32_t n_neighbors, int32_t global_pool, const fc_tensor* t
     e->global_pool = global_pool ? 1 : 0;
     fc::WeightTable wt(tensors, n_tensors);
     fc::build_dgcnn(*e, wt);
+    e->fp16_flag = (int*)e->arena.alloc_floats(1);
     FC_HIP(hipDeviceSynchronize());
     *out = e.release();
     FC_API_END
@@ -189,7 +190,6 @@ int fc_dgcnn_workspace_bytes(const fc_dgcnn* emb, int32_t B, int32_t M, size_t* 
 int fc_dgcnn_embed_f32(fc_dgcnn* emb, const float* pts, float* out, int32_t B, int32_t M, void* workspace, size_t workspace_bytes, void* stream) {
     FC_API_BEGIN
     if (!emb || !workspace) throw fc::Error(FC_ERR_INVALID, "fc_dgcnn_embed_f32: null handle / workspace");
-    if (!emb->fp16_flag) emb->fp16_flag = (int*)emb->arena.alloc_floats(1);
     // fast split-fp16 GEMMs first; the whole pass is repeated with the bf16-limb GEMMs if an activation left fp16's range
     fc::run_fp16_guarded(emb->fp16_flag, (hipStream_t)stream, [&] {
         fc::dgcnn_forward(*emb, pts, out, B, M, workspace, workspace_bytes, (hipStream_t)stream);

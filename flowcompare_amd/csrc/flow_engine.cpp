@@ -705,6 +705,7 @@ int fc_flow_create(const fc_flow_config* cfg, const fc_tensor* tensors, int32_t 
     f->cfg = *cfg;
     fc::WeightTable wt(tensors, n_tensors);
     fc::build_flow(*f, wt);
+    f->fp16_flag = (int*)f->arena.alloc_floats(1);
     FC_HIP(hipDeviceSynchronize());
     *out = f.release();
     FC_API_END
@@ -730,7 +731,6 @@ int fc_flow_logprob_f32(fc_flow* flow, const float* x, const float* ctx, const f
                         float* logprob, float* z_out, int32_t B, int32_t N, int32_t M, void* workspace, size_t workspace_bytes, void* stream) {
     FC_API_BEGIN
     if (!flow || !workspace) throw fc::Error(FC_ERR_INVALID, "fc_flow_logprob_f32: null flow / workspace");
-    if (!flow->fp16_flag) flow->fp16_flag = (int*)flow->arena.alloc_floats(1);
     // fast split-fp16 GEMMs first; the whole pass is repeated with the bf16-limb GEMMs if an activation left fp16's range
     fc::run_fp16_guarded(flow->fp16_flag, (hipStream_t)stream, [&] {
         fc::flow_forward(*flow, x, ctx, extra, eps, n_eps, logprob, z_out, B, N, M, workspace, workspace_bytes, (hipStream_t)stream);

@@ -79,6 +79,12 @@ typedef struct fc_paconv fc_paconv;  /* replaces models.PointNet2SSGSeg (models/
 
 int fc_abi_version(void);
 const char* fc_last_error(void);     /* thread-local, valid until the next failing call on this thread */
+/* Threading: handles are immutable after create, but a compute call uses the handle's range-guard word and the caller's
+ * workspace, so concurrent calls must use different handles (or be serialised by the caller); different handles and the
+ * fc_op_* / fc_stage_* / fc_change_* entry points may run concurrently on different streams.
+ * Arithmetic: GEMM-shaped work carries fp32-equivalent operands as two fp16 limbs; a compute call whose
+ * activations leave fp16's range (|x| >= 65504) is transparently repeated with bf16 limbs, so results stay fp32-accurate.  The
+ * flow / embedder compute calls therefore end with a stream synchronise. */
 
 /* ---- flow: Flow.log_prob / Flow.sample ------------------------------------------------------- */
 
