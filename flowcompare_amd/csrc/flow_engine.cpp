@@ -459,18 +459,23 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
                           hipStream_t s) {
     const Dims& d = f.d;
     const int ldh = std::max(d.H_pad, 32);
-    const int cur = run_mlp_hidden(f, pre, &in, nullptr, w, act, s);
-    int o = 0;
-    while (o == cur) ++o;
-    GemmEpi e{};
-    e.act = FC_ACT_NONE; e.C = w.h[o]; e.ldc = ldh; e.rows_valid = w.P;
-    ASeg a{w.h[cur], ldh};
-    launch_gemm(pre.out_layer, &a, w.P_pad, e, EPI_LINEAR, s);
-    launch_layernorm(w.h[o], ldh, d.A_in, w.P, s);
-    GemmEpi eq{};
-    eq.act = FC_ACT_NONE; eq.C = w.q; eq.ldc = d.I_pad; eq.rows_valid = w.P;
-    ASeg aq{w.h[o], ldh};
-    launch_gemm(at.q, &aq, w.P_pad, eq, EPI_LINEAR, s);
+    if (premlp_fusable(pre.in_layer, pre.mid, pre.out_layer, at.q) && in.lda >= pre.in_layer.K_pad) {
+        // the whole chain x1 -> MLP -> LayerNorm -> q in one kernel: the 64-row activation tile stays in LDS (premlp.hip)
+        launch_premlp(in.ptr, in.lda, pre.in_layer, pre.mid, pre.out_layer, at.q, act, w.q, d.I_pad, w.P_pad, w.P, s);
+    } else {
+        const int cur = run_mlp_hidden(f, pre, &in, nullptr, w, act, s);
+        int o = 0;
+        while (o == cur) ++o;
+        GemmEpi e{};
+        e.act = FC_ACT_NONE; e.C = w.h[o]; e.ldc = ldh; e.rows_valid = w.P;
+        ASeg a{w.h[cur], ldh};
+        launch_gemm(pre.out_layer, &a, w.P_pad, e, EPI_LINEAR, s);
+        launch_layernorm(w.h[o], ldh, d.A_in, w.P, s);
+        GemmEpi eq{};
+        eq.act = FC_ACT_NONE; eq.C = w.q; eq.ldc = d.I_pad; eq.rows_valid = w.P;
+        ASeg aq{w.h[o], ldh};
+        launch_gemm(at.q, &aq, w.P_pad, eq, EPI_LINEAR, s);
+    }
     launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad, w.kv16, s);
 }
 
