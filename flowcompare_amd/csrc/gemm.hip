@@ -175,7 +175,12 @@ void gemm_f32_kernel(const GemmParams p) {
         constexpr int TPR = KS / 4;                                 // threads (float4s) per A row
         constexpr int RPP3 = NT / TPR, A3 = BM / RPP3, W3N = (BN * CH + NT - 1) / NT;   // float4 loads of A, 16-byte loads of W per thread and stage
         char* smc = reinterpret_cast<char*>(smem);
-        const int lrow3 = tid / TPR, lc3 = (tid % TPR) * 4;
+        // Row slots are dealt to lanes so that the lanes one LDS store cycle serves (16 for ds_write_b64, 8 for ds_write_b128;
+        // stores see 32 banks) fall on distinct banks of the 80-byte-pitch image: with the natural order rows r and r+3 (b64)
+        // or r and r+1 (b128) overlapped, a 2-way conflict on the CU's scarcest path (VGPR -> LDS, ~80 B/clk).
+        const int rs3 = tid / TPR;
+        const int lrow3 = (F16 && KS == 16) ? 8 * (rs3 >> 3) + ((rs3 >> 2) & 1) + 2 * (rs3 & 3) : rs3, lc3 = (tid % TPR) * 4;
+#define FC_WROW(SLOT_) ((F16 && KS == 16) ? 8 * ((SLOT_) >> 3) + (((SLOT_) >> 1) & 3) + 4 * ((SLOT_) & 1) : (SLOT_))
         const int KT16 = p.KT * 2, KTS = p.KT * U;
         const unsigned short* const Wl = F16 ? p.W2 : p.W3;
         float amax = 0.f;
@@ -197,7 +202,7 @@ void gemm_f32_kernel(const GemmParams p) {
             _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
                 int c_ = tid + NT * i;                                                                             \
                 c_ = c_ < BN * CH ? c_ : BN * CH - 1;     /* unconditional load (a guarded one sends the staging registers through scratch) */ \
-                const int row_ = c_ / CH, part_ = c_ - row_ * CH;                                                  \
+                const int slot_ = c_ / CH, part_ = c_ - slot_ * CH, row_ = FC_WROW(slot_);                         \
                 const int sub_ = part_ / (NL * 2), q2_ = part_ - sub_ * (NL * 2);   /* k16 tile of the stage; limb*2 + half */ \
                 const uint4 t_ = *reinterpret_cast<const uint4*>(Wl + ((size_t)(n0 + row_) * KT16 + (KT_) * KSUB + sub_) * (NL * 16) + q2_ * 8); \
                 rw3_##S_[4 * i] = t_.x; rw3_##S_[4 * i + 1] = t_.y; rw3_##S_[4 * i + 2] = t_.z; rw3_##S_[4 * i + 3] = t_.w; \
@@ -231,7 +236,7 @@ void gemm_f32_kernel(const GemmParams p) {
                 }                                                                                                  \
             }                                                                                                      \
             _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
-                const int c_ = tid + NT * i, row_ = c_ / CH, part_ = c_ - row_ * CH;                               \
+                const int c_ = tid + NT * i, slot_ = c_ / CH, part_ = c_ - slot_ * CH, row_ = FC_WROW(slot_);      \
                 const int sub_ = part_ / (NL * 2), q2_ = part_ - sub_ * (NL * 2);                                  \
                 if (BN * CH % NT == 0 || c_ < BN * CH)                                                             \
                     *reinterpret_cast<uint4*>(smc + (ST_) * STAGE3 + (BM + row_) * ROWB + (q2_ >> 1) * LIMB_B + sub_ * 32 + (q2_ & 1) * 16) = \
@@ -319,6 +324,7 @@ void gemm_f32_kernel(const GemmParams p) {
             if (amax >= 65504.0f) atomicOr(p.ovf, 1);               // some |x| does not fit fp16: the caller repeats with bf16 limbs
         }
 #undef FC_MMA3
+#undef FC_WROW
 #undef FC_GLOAD3
 #undef FC_LSTORE3
     } else {
