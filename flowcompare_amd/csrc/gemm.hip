@@ -42,7 +42,6 @@ struct GemmParams {
     int N_pad;
     int nbm, nbn;
     int col_group;      // > 0: row-band / column-group tile order for weight matrices that do not fit L2
-    int stagger;
     GemmEpi e;
 };
 
@@ -94,10 +93,6 @@ void gemm_f32_kernel(const GemmParams p) {
     nvalid = nvalid < 0 ? 0 : (nvalid > TN ? TN : nvalid); // W / bias are allocated zero-padded to the grid, the k-loop is branch free)
     const GemmEpi& e = p.e;
 
-    // Two workgroups share a CU and run the same program on equal work: left alone they move in lockstep (both in the
-    // prologue, at the barrier or in the epilogue together), which leaves the matrix pipe idle while they do.  A one-off
-    // offset for the second resident set de-phases them for the rest of the launch (placement only changes speed).
-    if (p.stagger && blockIdx.x >= 256 && blockIdx.x < 512) __builtin_amdgcn_s_sleep(40);
 
     // ---- accumulators start from the epilogue's additive terms (bias, rank-1 extra-context term, residual), so their
     //      global loads overlap the first tile's loads instead of forming a dependent tail after the last MFMA.
@@ -165,7 +160,7 @@ void gemm_f32_kernel(const GemmParams p) {
         // max-reduced and a launch that met one >= 65504 raises *p.ovf; the entry point then repeats the whole call with the
         // bf16 limbs (unbounded range).  Weights with such entries never get an fp16 image (PackedLinear.W2 == nullptr).
         constexpr bool F16 = VAR >= 5;
-        constexpr int KS = VAR == 6 ? 32 : 16;                      // k extent of one LDS stage (VAR 6: experiment, one-deep prefetch)
+        constexpr int KS = 16;                                      // k extent of one LDS stage (32 with one-deep prefetch measured 13 % slower)
         constexpr int KSUB = KS / 16, U = 32 / KS;
         constexpr int NL = F16 ? 2 : 3;                             // limbs
         constexpr int LIMB_B = KS * 2;                              // bytes of one limb of a row
@@ -179,9 +174,9 @@ void gemm_f32_kernel(const GemmParams p) {
         // stores see 32 banks) fall on distinct banks of the 80-byte-pitch image: with the natural order rows r and r+3 (b64)
         // or r and r+1 (b128) overlapped, a 2-way conflict on the CU's scarcest path (VGPR -> LDS, ~80 B/clk).
         const int rs3 = tid / TPR;
-        const int lrow3 = (F16 && KS == 16) ? 8 * (rs3 >> 3) + ((rs3 >> 2) & 1) + 2 * (rs3 & 3) : rs3, lc3 = (tid % TPR) * 4;
-#define FC_WROW(SLOT_) ((F16 && KS == 16) ? 8 * ((SLOT_) >> 3) + (((SLOT_) >> 1) & 3) + 4 * ((SLOT_) & 1) : (SLOT_))
-        const int KT16 = p.KT * 2, KTS = p.KT * U;
+        const int lrow3 = F16 ? 8 * (rs3 >> 3) + ((rs3 >> 2) & 1) + 2 * (rs3 & 3) : rs3, lc3 = (tid % TPR) * 4;
+#define FC_WROW(SLOT_) (F16 ? 8 * ((SLOT_) >> 3) + (((SLOT_) >> 1) & 3) + 4 * ((SLOT_) & 1) : (SLOT_))
+        const int KT16 = p.KT * 2;
         const unsigned short* const Wl = F16 ? p.W2 : p.W3;
         float amax = 0.f;
         // two register sets: the tile loaded in iteration kt is only converted/stored in iteration kt+1, so a global load has a
@@ -285,34 +280,21 @@ void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) corr[i][j][r] = 0.f;
         }
-        if constexpr (KS == 16) {
-            // KT16 is even (K_pad is a multiple of 32).  Stage s of LDS holds tile kt (s = kt & 1); register set s holds tile kt+1 ... kt+2.
-            FC_GLOAD3(0, 0)
-            FC_LSTORE3(0, 0)
-            FC_GLOAD3(1, 1)
+        // KT16 is even (K_pad is a multiple of 32).  Stage s of LDS holds tile kt (s = kt & 1); register set s holds tile kt+1 ... kt+2.
+        FC_GLOAD3(0, 0)
+        FC_LSTORE3(0, 0)
+        FC_GLOAD3(1, 1)
+        __syncthreads();
+        for (int kt = 0; kt < KT16; kt += 2) {
+            const int k2 = kt + 2 < KT16 ? kt + 2 : KT16 - 1, k3 = kt + 3 < KT16 ? kt + 3 : KT16 - 1;   // tail re-loads: branch-free loop
+            FC_GLOAD3(0, k2)
+            FC_MMA3(0)
+            FC_LSTORE3(1, 1)
             __syncthreads();
-            for (int kt = 0; kt < KT16; kt += 2) {
-                const int k2 = kt + 2 < KT16 ? kt + 2 : KT16 - 1, k3 = kt + 3 < KT16 ? kt + 3 : KT16 - 1;   // tail re-loads: branch-free loop
-                FC_GLOAD3(0, k2)
-                FC_MMA3(0)
-                FC_LSTORE3(1, 1)
-                __syncthreads();
-                FC_GLOAD3(1, k3)
-                FC_MMA3(1)
-                FC_LSTORE3(0, 0)
-                __syncthreads();
-            }
-        } else {
-            FC_GLOAD3(0, 0)
+            FC_GLOAD3(1, k3)
+            FC_MMA3(1)
             FC_LSTORE3(0, 0)
             __syncthreads();
-            for (int kt = 0; kt < KTS; ++kt) {
-                const int ktn = kt + 1 < KTS ? kt + 1 : kt;
-                FC_GLOAD3(0, ktn)
-                FC_MMA3(kt & 1)
-                FC_LSTORE3(0, (kt + 1) & 1)
-                __syncthreads();
-            }
         }
         if constexpr (F16) {
 #pragma unroll
@@ -527,7 +509,7 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 5, g_gemm_stagger = 0, g_gemm_colgroup = 10, g_gemm_bigtile = 1, g_gemm_k32 = 0, g_fused_spline = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 1, g_fused_spline = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
@@ -553,7 +535,7 @@ bool Fp16Guard::overflowed() {
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds_main = VAR == 6 ? 2 * (size_t)(BM + BN) * 144 : VAR == 5 ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds_main = VAR == 5 ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
     constexpr size_t lds_epi = EPI == EPI_SPLINE ? ((size_t)BM * (BN + 1) + (size_t)BM * 9) * sizeof(float) : 0;   // tile + <= 9 dims of log-dets
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
@@ -594,7 +576,6 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     GemmEpi e = e_in;
     e.flops_hint = 2.0 * (double)(e.rows_valid > 0 ? e.rows_valid : rows_alloc) * (double)(L.n_true ? L.n_true : L.N_pad) *
                    (double)(L.k_true ? L.k_true : L.K_pad);
-    p.stagger = g_gemm_stagger;
     p.W = L.W; p.W3 = L.W3; p.W2 = L.W2; p.ovf = t_fp16_flag; p.K_pad = L.K_pad; p.bias = L.bias; p.colvec = L.colvec; p.N_pad = L.N_pad;
     p.e = e;
     const bool split = (g_gemm_variant == 3 || g_gemm_variant == 5) && L.W3 != nullptr;
@@ -615,8 +596,7 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             else if (split && g_gemm_bigtile == 2 && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 3>(p, s); }
             else {
                 p.nbm = rows_alloc / 128;
-                if (f16 && g_gemm_k32) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 6>(p, s);
-                else if (f16) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 5>(p, s);
+                if (f16) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 5>(p, s);
                 else if (split) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 3>(p, s);
                 else if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
                 else if (g_gemm_variant == 1) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 1>(p, s);

@@ -23,18 +23,16 @@ struct TmpBuf {
     return FC_OK;
 
 namespace fc { long gemm_fp16_fallbacks(); }
-namespace fc { extern int g_gemm_variant, g_gemm_stagger, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_gemm_k32, g_fused_spline, g_premlp_fused; }
+namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused; }
 
 extern "C" {
 
 /* tuning knobs for profiles/kernel_bench.py (not part of the stable ABI surface in fcflow.h on purpose) */
 int fc_debug_set(int32_t key, int32_t value) {
     if (key == 0) fc::g_gemm_variant = value;
-    else if (key == 1) fc::g_gemm_stagger = value;
     else if (key == 2) fc::g_gemm_colgroup = value;
     else if (key == 3) fc::g_gemm_bigtile = value;
     else if (key == 5) fc::g_attn_fp16 = value;
-    else if (key == 6) fc::g_gemm_k32 = value;
     else if (key == 7) fc::g_fused_spline = value;
     else if (key == 8) fc::g_premlp_fused = value;
     else return FC_ERR_INVALID;

@@ -28,7 +28,7 @@ def run(fn):
 for kv in filter(None, os.environ.get("KNOBS", "").split(",")):      # e.g. KNOBS=2=6 (column group of the tile order)
     engine.lib().fc_debug_set(*map(int, kv.split("=")))
 print(f"rows={rows} knobs={os.environ.get('KNOBS', '')}")
-variants = [(int(v[0]), int(v[1]), int(v[2:] or 0)) for v in os.environ.get("VARIANTS", "50").split(",")]   # (loop variant, big tile 0/1/2, k32 0/1)
+variants = [(int(v[0]), int(v[1])) for v in os.environ.get("VARIANTS", "51").split(",")]   # (loop variant 5/3/2, big tile 0/1/2)
 shapes = [("pre_in", 256, 150, "gelu", False), ("pre_mid", 256, 256, "gelu", True), ("pre_out", 256, 256, "none", False),
           ("q_proj", 64, 256, "none", False), ("cpl_in", 512, 214, "gelu", False), ("cpl_mid", 512, 512, "gelu", True),
           ("cpl_mid_noact", 512, 512, "none", False), ("cpl_mid_gelu", 512, 512, "gelu", False), ("cpl_mid_res", 512, 512, "none", True), ("affine_out", 300, 512, "none", False), ("spline_out", 3750, 512, "none", False),
@@ -41,13 +41,13 @@ for name, N, K, act, res in shapes:
     W = ((torch.rand(N, K, generator=g) - 0.5) * K ** -0.5).to(dev)
     b = torch.rand(N, generator=g).to(dev)
     r = torch.rand(rows, N, generator=g).to(dev) if res else None
-    for var, stag, k32 in variants:
-        engine.lib().fc_debug_set(0, var); engine.lib().fc_debug_set(3, stag); engine.lib().fc_debug_set(6, k32)
+    for var, stag in variants:
+        engine.lib().fc_debug_set(0, var); engine.lib().fc_debug_set(3, stag)
         rep = run(lambda: engine.op_linear(x, W, b, r, act))
         for p in rep:
             if "gemm" in p["kernel"]:
                 ms = p["ms"] / p["launches"]
-                print(f"{name:14s} N={N:5d} K={K:4d} act={act:5s} res={int(res)} var={var} bigtile={stag} k32={k32} {ms*1e3:9.1f} us  {2.0*rows*N*K/ms/1e9:7.1f} TF   {p['kernel'][21:52]}")
+                print(f"{name:14s} N={N:5d} K={K:4d} act={act:5s} res={int(res)} var={var} bigtile={stag} {ms*1e3:9.1f} us  {2.0*rows*N*K/ms/1e9:7.1f} TF   {p['kernel'][21:52]}")
 
 for B, N, M, D in [(16, 4096, 4096, 64), (2, 16384, 16384, 64), (16, 1024, 1250, 64)]:
     if only and "attention" not in only:
