@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, HIP-event timi
 region) and `cpu_baseline` (the pinned CPU oracle timed on the host cores on a bounded sample of the same workload).
 """
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -126,7 +127,8 @@ def main():
     cfg = fa.named_config(args.config, **over)
     torch.manual_seed(0)                                  # same random-init weights on every rank
     log(f"rank {rank}: building {args.config} ({cfg['n_flow_layers']} layers) ...")
-    md = fa.initialize_flow(cfg, device=dev, mode="test")
+    with contextlib.redirect_stdout(sys.stderr):          # the reference API prints its parameter count: stdout carries only the JSON line
+        md = fa.initialize_flow(cfg, device=dev, mode="test")
     B, N = args.batch, args.points
     e0, e1, extra, g = synth_pairs(B, N, N, 1000 + rank, dev)   # every rank owns different scenes
     batch = (e0, e1, extra if cfg["extra_z_value_context"] else None)
