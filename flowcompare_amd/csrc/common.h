@@ -37,6 +37,7 @@ constexpr int COL_PAD = 32;    // feature widths are padded to this (GEMM BK / M
 // name (as rocprofv3 prints it), launches, total milliseconds and the useful FLOPs / algorithmic bytes the launches
 // processed.  bench.py derives its `roofline` object from this over the timed region.
 bool prof_enabled();
+void prof_filter(const char* substr);
 struct ProfScope {
     bool on;
     hipStream_t s;

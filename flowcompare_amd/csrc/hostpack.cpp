@@ -16,6 +16,7 @@ namespace {
 struct ProfRec { hipEvent_t a, b; int name; double flops, bytes; };
 struct ProfState {
     bool on = false;
+    std::string filter;               // non-empty: only launches whose kernel name contains it are bracketed
     std::vector<std::string> names;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
@@ -35,6 +36,7 @@ ProfState g_prof;
 }  // namespace
 bool prof_enabled() { return g_prof.on; }
 ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : on(g_prof.on), s(stream) {
+    if (on && !g_prof.filter.empty() && !strstr(name, g_prof.filter.c_str())) on = false;
     if (!on) return;
     ProfRec r{g_prof.ev(), g_prof.ev(), g_prof.name_id(name), flops, bytes};
     (void)hipEventRecord(r.a, s);
@@ -45,6 +47,7 @@ ProfScope::~ProfScope() {
     if (on && slot >= 0) (void)hipEventRecord(g_prof.recs[slot].b, s);
 }
 void prof_set(bool on) { g_prof.on = on; }
+void prof_filter(const char* substr) { g_prof.filter = substr ? substr : ""; }
 void prof_reset() {
     for (auto& r : g_prof.recs) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }
     g_prof.recs.clear();

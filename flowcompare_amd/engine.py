@@ -25,7 +25,7 @@ EXPORTS = [
     "fc_flow_logprob_f32", "fc_flow_inverse_f32",
     "fc_dgcnn_create", "fc_dgcnn_destroy", "fc_dgcnn_out_dim", "fc_dgcnn_workspace_bytes", "fc_dgcnn_embed_f32",
     "fc_paconv_create", "fc_paconv_destroy", "fc_paconv_out_dim", "fc_paconv_workspace_bytes", "fc_paconv_embed_f32", "fc_op_fps_f32",
-    "fc_profile_enable", "fc_profile_reset", "fc_profile_report",
+    "fc_profile_enable", "fc_profile_reset", "fc_profile_filter", "fc_profile_report",
     "fc_op_linear_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
     "fc_stage_fps_f32", "fc_stage_co_unit_sphere_f32", "fc_clamp_infs_f32", "fc_change_map_f32",
 ]
@@ -408,6 +408,11 @@ def op_rqspline(x, params, num_bins, inverse=False):
 # ---------------------------------------------------------------- in-library kernel timing
 def profile_enable(on=True):
     _check(lib().fc_profile_enable(int(bool(on))))
+
+
+def profile_filter(kernel_substr=None):
+    """Bracket only launches whose kernel name contains `kernel_substr` (None = all)."""
+    _check(lib().fc_profile_filter(kernel_substr.encode() if kernel_substr else None))
 
 
 def profile_reset():
