@@ -49,7 +49,7 @@ struct GemmParams {
 constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN <= 128 ? 2 : 1)))   // two resident workgroups per CU for the <= 128-wide tiles
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN > 128 ? 1 : (BM == 128 && WM * WN == 8) ? 4 : 2)))   // resident waves per SIMD the register budget must allow
 void gemm_f32_kernel(const GemmParams p) {
     constexpr int NT = WM * WN * 64;                       // 4 or 8 waves per workgroup
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -509,7 +509,7 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 1, g_fused_spline = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_fused_spline = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
@@ -589,14 +589,17 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             else launch_cfg<128, 64, 4, 1, EPI_LINEAR>(p, s);
         } else if (L.N_pad % 128 == 0 || L.N_pad > 320 || (split && L.n_alloc >= round_up(L.N_pad, 128))) {
             // (with the split-bf16 loop two co-resident 128x128 workgroups beat the one-wave-per-SIMD 128x320 tile even at N = 320)
-            // 8-wave 256x128 workgroups for the wide layers (N >= 1024, e.g. the 3750-column spline parameter layer: +3 % measured);
-            // knob 3: 0 = never, 1 = wide layers (default), 2 = every layer
+            // Default for the split-fp16 loop: 128x128 tile on EIGHT waves of 32x64 (64 accumulator registers per lane instead of
+            // 128 -> 118 VGPRs -> 4 waves per SIMD instead of 2): +4 ... +19 % over four waves of 64x64 on every layer shape, and
+            // better than the 8-wave 256x128 tile on the wide layers.  knob 3: 3 = that (default), 0 = four 64x64 waves,
+            // 1 = 256x128 for N >= 1024, 2 = 256x128 everywhere
             const bool big = g_gemm_bigtile == 2 || (g_gemm_bigtile == 1 && L.N_pad >= 1024);
             if (f16 && big && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 5>(p, s); }
             else if (split && g_gemm_bigtile == 2 && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 3>(p, s); }
             else {
                 p.nbm = rows_alloc / 128;
-                if (f16) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 5>(p, s);
+                if (f16 && g_gemm_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_LINEAR, 5>(p, s);
+                else if (f16) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 5>(p, s);
                 else if (split) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 3>(p, s);
                 else if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
                 else if (g_gemm_variant == 1) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 1>(p, s);
@@ -612,7 +615,9 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         if ((K != 4 && K != 8 && K != 16) || L.N_pad != spline_ncols(e.d2, K) || !e.xbuf || !e.ldj_part || e.ldj_pitch < (size_t)rows_alloc)
             throw Error(FC_ERR_INVALID, "launch_gemm: bad fused-spline arguments (layout of spline.h, per-tile log-det buffer)");
         p.nbm = rows_alloc / 128;
-        if (f16) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 5>(p, s); else launch_cfg<128, 128, 2, 2, EPI_SPLINE, 3>(p, s);
+        if (f16 && g_gemm_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_SPLINE, 5>(p, s);
+        else if (f16) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 5>(p, s);
+        else launch_cfg<128, 128, 2, 2, EPI_SPLINE, 3>(p, s);
     } else {
         if (!L.bias || L.N_pad % 64 != 0) throw Error(FC_ERR_INVALID, "launch_gemm: pair-packed epilogue needs bias and N_pad % 64 == 0");
         p.nbm = rows_alloc / 128;
