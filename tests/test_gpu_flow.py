@@ -192,3 +192,35 @@ def test_out_of_fp16_range_activations_repeat_on_the_bf16_limb_path():
         err = (lp.cpu().double() - ref).abs().max().item()
         print(f"alpha {alpha:g}: fallback {expect_fallback}, max |log-prob - fp64 golden| {err:.2e}")
         assert torch.isfinite(lp).all() and err < PER_POINT_TOL and abs(float(bpd) - float(fx.a["bpd_f64"])) < BPD_TOL
+
+
+def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
+    """The shipped fast paths (split-fp16 GEMM on eight-wave tiles, fused spline epilogue, fused pre-attention chain, split-fp16
+    attention) against the slower variants they replaced, which stay in the library as fallbacks: same log-probs within the
+    fp32 noise of a 4-layer flow at the real layer widths."""
+    from flowcompare_amd import engine
+    lib = engine.lib()
+    cfg = fa.named_config("c2_dgcnn_attn_spline", n_flow_layers=4, sample_size=300)
+    torch.manual_seed(7)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    g = torch.Generator().manual_seed(8)
+    B, N, M = 2, 300, 280
+    e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
+    eps = [torch.randn(B, N, 294, generator=g).to(DEV)]
+    batch = (e0.to(DEV), e1.to(DEV), None)
+    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 1}
+    try:
+        _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+        for name, knobs in (("unfused spline", {7: 0}), ("unfused pre-attention chain", {8: 0}), ("fp32-input attention", {5: 0}),
+                            ("four-wave tile", {3: 0}), ("256x128 tile", {3: 2}), ("bf16-limb GEMM", {0: 3}), ("fp32-input MFMA GEMM", {0: 2})):
+            for k, v in knobs.items():
+                lib.fc_debug_set(k, v)
+            _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+            for k in knobs:
+                lib.fc_debug_set(k, defaults[k])
+            err = (lp - ref).abs().max().item()
+            print(f"{name}: max |log-prob - default path| {err:.2e}")
+            assert err < 5e-4, name
+    finally:
+        for k, v in defaults.items():
+            lib.fc_debug_set(k, v)
