@@ -423,9 +423,25 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
 struct FlowWs {
     float *xa, *xb, *h[3], *q, *a, *ctxp, *kv, *xin, *rowscal, *spl, *cbuf;
     void* kv16;      // K / V limb images of the layer in flight (split-fp16 attention)
-    float* ldjp;     // per-column-tile log-det partials of the fused spline epilogue, [tiles][P_pad]
+    float* ldjp;     // log-det partial slots of the fused spline / pair epilogues, [ldj_slots][P_pad] (ldj_slot_count)
+    int ldj_slots;
     int P, P_pad, Pc, Pc_pad, ldkv;
 };
+// Log-det partial slots (rows of FlowWs::ldjp): one per 128-column tile of the fused spline epilogue, two (one per wave column)
+// per 128-column tile of a pair-packed epilogue (affine coupling, augmenter, CIF slice) on the 8-wave split-fp16 tile.  The
+// epilogues ACCUMULATE into their own slots over the layers; flow_forward zeroes the buffer first and reduces it once at the end,
+// in a fixed order (bit-reproducible, unlike atomics on log-prob).
+static int ldj_slot_count(const fc_flow& f) {
+    int n = f.cfg.flow_type == FC_FLOW_SPLINE ? f.d.ldp / 128 : 0;
+    auto pair = [&](const PackedLinear& L) { if (L.N_pad > 0) n = std::max(n, 2 * (round_up(L.N_pad, 128) / 128)); };
+    if (f.has_augment) pair(f.aug_net.out_layer);
+    for (const BlockPack& b : f.blocks) {
+        if (f.cfg.flow_type == FC_FLOW_AFFINE) pair(b.net.out_layer);
+        if (b.has_cif) { pair(b.cif.dist.out_layer); pair(b.cif.aff.out_layer); }
+    }
+    return n;
+}
+
 static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t bytes, bool dry, size_t* need) {
     const Dims& d = f.d;
     FlowWs w{};
@@ -444,7 +460,8 @@ static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t by
     w.rowscal = c.floats((size_t)w.P_pad);
     w.spl = c.floats(d.ldp ? (size_t)w.P_pad * d.ldp : 1);
     w.cbuf = c.floats(d.nz > 0 ? (size_t)w.P_pad * d.nz_pad : 1);
-    w.ldjp = c.floats(f.cfg.flow_type == FC_FLOW_SPLINE ? (size_t)(d.ldp / 128) * w.P_pad : 1);
+    w.ldj_slots = ldj_slot_count(f);
+    w.ldjp = c.floats(std::max<size_t>((size_t)w.ldj_slots * w.P_pad, 1));
     w.kv16 = c.bytes(f.n_attn > 0 ? std::max<size_t>(attention_limb_ws_bytes(w.Pc_pad, d.I_pad), 16) : 16);
     if (need) *need = c.off + 256;
     return w;
@@ -500,6 +517,7 @@ static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, c
         GemmEpi e{};
         e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = d.d1_pad; e.d2 = d.d2; e.scale_fn = c.affine_scale_fn;
         e.logprob = logprob; e.rows_valid = w.P; e.inverse = inverse;
+        if (!inverse) { e.ldj_part = w.ldjp; e.ldj_pitch = (size_t)w.P_pad; }
         launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_AFFINE, s);
     } else if (c.flow_type == FC_FLOW_SPLINE && !inverse && gemm_split_enabled() && b.net.out_layer.W3 != nullptr) {
         // forward: the parameter GEMM evaluates the splines in its epilogue; only per-tile log-det partials leave the kernel
@@ -524,6 +542,7 @@ static void run_cif_dist(fc_flow& f, const CifPack& cp, FlowWs& w, float* xc, Ge
     const int cur = run_mlp_hidden(f, cp.dist, &in, nullptr, w, FC_ACT_GELU, s);
     ASeg a{w.h[cur], std::max(f.d.H_pad, 32)};
     e.clamp = f.cfg.clamp_dist; e.d2 = f.d.nz; e.rows_valid = w.P;
+    if (!e.inverse) { e.ldj_part = w.ldjp; e.ldj_pitch = (size_t)w.P_pad; }
     launch_gemm(cp.dist.out_layer, &a, w.P_pad, e, epi, s);
 }
 static void run_cif_affine(fc_flow& f, const CifPack& cp, FlowWs& w, float* xc, float* logprob, bool inverse, hipStream_t s) {
@@ -534,6 +553,7 @@ static void run_cif_affine(fc_flow& f, const CifPack& cp, FlowWs& w, float* xc, 
     GemmEpi e{};
     e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = 0; e.split = d.d1; e.split_pad = d.d1_pad; e.d2 = d.D; e.scale_fn = FC_SCALE_SIGMOID;
     e.post_scale = cp.post_scale; e.logprob = logprob; e.rows_valid = w.P; e.inverse = inverse;
+    if (!inverse) { e.ldj_part = w.ldjp; e.ldj_pitch = (size_t)w.P_pad; }
     launch_gemm(cp.aff.out_layer, &a, w.P_pad, e, EPI_AFFINE, s);
 }
 
@@ -578,7 +598,7 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
     int eps_i = 0;
 
     launch_fill(logprob, 0.f, (size_t)w.P, s);
-    const int ldj_tiles = c.flow_type == FC_FLOW_SPLINE ? d.ldp / 128 : 0;     // fused spline epilogues accumulate per-tile log-dets here
+    const int ldj_tiles = w.ldj_slots;                                         // epilogues accumulate their log-det partials here
     if (ldj_tiles) launch_fill(w.ldjp, 0.f, (size_t)ldj_tiles * w.P_pad, s);
     float* xc = w.xa;
     float* xn = w.xb;
@@ -595,6 +615,7 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
         GemmEpi e{};
         e.xbuf = xc; e.ldx = d.ldx; e.d2 = d.D - d.Din; e.logprob = logprob; e.eps = eps[eps_i++];
         e.d_in = d.Din; e.d1 = d.d1; e.d1_pad = d.d1_pad; e.rows_valid = w.P;
+        e.ldj_part = w.ldjp; e.ldj_pitch = (size_t)w.P_pad;
         ASeg a{w.h[cur], ldh};
         launch_gemm(f.aug_net.out_layer, &a, w.P_pad, e, EPI_AUGMENT, s);
     } else {

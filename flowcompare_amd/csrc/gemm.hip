@@ -501,7 +501,8 @@ void gemm_f32_kernel(const GemmParams p) {
                 const float tot = half_wave_sum(lsum[i][r]);
                 const int row = wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (li == 0 && row < e.rows_valid) {
-                    if (p.nbn * WN > 1) atomicAdd(e.logprob + row, tot);
+                    if (WN > 1 || BN < 320) e.ldj_part[(size_t)(bn * WN + wc) * e.ldj_pitch + row] += tot;     // own slot: reproducible
+                    else if (p.nbn * WN > 1) atomicAdd(e.logprob + row, tot);
                     else e.logprob[row] += tot;
                 }
             }
@@ -621,7 +622,16 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     } else {
         if (!L.bias || L.N_pad % 64 != 0) throw Error(FC_ERR_INVALID, "launch_gemm: pair-packed epilogue needs bias and N_pad % 64 == 0");
         p.nbm = rows_alloc / 128;
-        if (epi_kind == EPI_AFFINE) { if (split) launch_cfg<128, 320, 4, 1, EPI_AFFINE, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_AFFINE>(p, s); }
+        // forward direction inside a guard scope: 128x128 tile on eight waves with the split-fp16 loop (a wave's 64 columns are one
+        // [first 32 | second 32] pair block); log-dets go to the caller's slot buffer.  Otherwise (inverse, bf16-limb fallback
+        // pass, fp32 variants): the 128x320 tile whose workgroup owns whole rows.
+        if (f16 && e.ldj_part && !e.inverse && g_gemm_bigtile == 3) {
+            if (e.ldj_pitch < (size_t)rows_alloc) throw Error(FC_ERR_INVALID, "launch_gemm: log-det slot pitch smaller than the row count");
+            if (epi_kind == EPI_AFFINE) launch_cfg<128, 128, 4, 2, EPI_AFFINE, 5>(p, s);
+            else if (epi_kind == EPI_AUGMENT) launch_cfg<128, 128, 4, 2, EPI_AUGMENT, 5>(p, s);
+            else launch_cfg<128, 128, 4, 2, EPI_SLICE, 5>(p, s);
+        }
+        else if (epi_kind == EPI_AFFINE) { if (split) launch_cfg<128, 320, 4, 1, EPI_AFFINE, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_AFFINE>(p, s); }
         else if (epi_kind == EPI_AUGMENT) { if (split) launch_cfg<128, 320, 4, 1, EPI_AUGMENT, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_AUGMENT>(p, s); }
         else { if (split) launch_cfg<128, 320, 4, 1, EPI_SLICE, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_SLICE>(p, s); }
     }
