@@ -1,18 +1,21 @@
-// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32) with fused epilogues.
+// The GEMM of the flow on the CDNA4 matrix cores, with fused epilogues.
 //
 //   C[rows, N_pad] = epilogue( sum_seg A_seg[rows, k_seg] @ W[N_pad, K_pad]^T )
 //
-// Every Linear of the flow (coupling MLPs, pre-attention MLPs, q/kv projections, the folded
-// ActNorm+LinearLU matrix, DGCNN 1x1 convs) goes through this kernel.  fp32-in / fp32-accumulate MFMA is
-// bit-for-bit an fmaf chain, which is what the 1e-4 nats parity gate over 115 chained layers needs
-// (DESIGN.md §numerics); its peak is 157.3 TFLOP/s, the roofline this kernel is measured against.
+// Every Linear of the flow (coupling MLPs, q/kv projections, the folded ActNorm+LinearLU matrix, DGCNN / PAConv 1x1
+// convolutions) goes through gemm_f32_kernel; operands and results are fp32 in memory, the products run in one of three
+// main loops selected by the template parameter VAR:
+//   VAR 5  split-fp16, the default: each operand as two fp16 limbs (hi + lo'/2048, 2^-24 relative), 3 v_mfma_f32_32x32x16_f16
+//          per product block, main and cross-product fp32 accumulators; needs the caller's Fp16Guard scope (|x| < 65504);
+//   VAR 3  split-bf16: three bf16 limbs, 6 MFMAs per block, unbounded range -- the pass a guarded call is repeated with;
+//   VAR 0-2 fp32-input MFMA (v_mfma_f32_32x32x2_f32, an exact fmaf chain): the first build's loop, kept for A/B and tests.
+// Epilogues (EPI): LINEAR (bias, rank-1 extra-context term, residual, activation), SPLINE (forward rational-quadratic spline
+// coupling on the tile the workgroup just produced), AFFINE / AUGMENT / SLICE (pair-packed [first 32 | second 32] columns).
 //
-// Layout: both operands are K-contiguous in memory (activations [rows][K], weights [N][K] exactly like
-// torch.nn.Linear.weight), so one ds_read_b128 per lane feeds FOUR MFMA k-steps of an operand tile:
-// lane (i = lane&31, h = lane>>5) holds element e of its float4 as the k = 8g + 4h + e operand.
-// LDS rows are 32 floats + 4 pad (144 B): conflict-free for ds_read_b128 (16 lanes -> 16 distinct 16-B slots).
-// Global -> LDS goes through registers (prefetch of tile t+1 is issued before the MFMAs of tile t, written
-// after them): one barrier per 32-deep K tile.
+// Layout: both operands are K-contiguous in memory (activations [rows][K], weights [N][K] exactly like torch.nn.Linear.weight;
+// limb images [N][K/16][limb][16]), so one ds_read_b128 per lane is one MFMA operand.  Global -> LDS goes through registers
+// (split loops: two-deep prefetch, whole-vector staging values, double-buffered LDS rows with a 16-byte pad).
+// Shipped tile for the split-fp16 loop: 128x128 on eight waves of 32x64 (118 VGPRs, 4 waves per SIMD).
 #include "common.h"
 #include "activations.h"
 #include "spline.h"
