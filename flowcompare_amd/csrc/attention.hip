@@ -1,4 +1,6 @@
-// Single-head cross attention of the flow's pre-conditioner, flash style, on fp32 MFMA.
+// Single-head cross attention of the flow's pre-conditioner, flash style.  Two kernels: attn16_kernel (split-fp16 operands on
+// the 16-bit matrix cores, the default for head dims <= 64 inside an Fp16Guard scope; further down) and attn_kernel (fp32-input
+// MFMA; head dim 128, the range-fallback pass, and the first build's kernel), described here:
 //   out[b, i, :] = softmax_j( q[b,i,:] . k[b,j,:] ) v[b,j,:]        (models/perceiver.py:106-113)
 // q arrives PRE-SCALED by inner_dim^-0.5 * log2(e) (folded into the packed q projection), so the softmax
 // is exp2(S - max).  The [N, M] score matrix is never materialised (the reference materialises [B,N,M]).
