@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[h2][r] = sm[r] + sc[r] * (1.0f / 2048.0f);
+            for (int r = 0; r < 16; ++r) s[h2][r] = fmaf(sc[r], 1.0f / 2048.0f, sm[r]);
         }
         // ---- mask the tail keys of the last tile
         if (t * 64 + 64 > p.M) {
