@@ -110,7 +110,10 @@ struct GemmEpi {
     int act = FC_ACT_NONE;
     const float* residual = nullptr; int ldr = 0;
     const float* rowscal = nullptr;          // [rows] (extra context per point), used with PackedLinear.colvec
-    float* C = nullptr; int ldc = 0;
+    float* C = nullptr; int ldc = 0;          // may be null when only the limb image C16 is wanted
+    unsigned short* C16 = nullptr;            // optional: the output as fp16 limb image [rows][N_pad/16][hi 16 | lo' 16] (operand image of a
+                                              // following split-fp16 GEMM, which then copies it instead of re-splitting it per column tile)
+    const unsigned short* A16 = nullptr;      // input: the A operand given as such an image (single segment of K_pad columns)
     // EPI_AFFINE (W pair-packed [s 32 | t 32] x pairs): in-place y2 = x2*s + t on xbuf, logprob[row] += sum log s
     // EPI_AUGMENT (W pair-packed [mu 32 | logsigma 32]): z2 = mu + eps*sigma scattered into xbuf, logprob += -log N(z2)
     float* xbuf = nullptr; int ldx = 0;
@@ -146,6 +149,7 @@ struct Fp16Guard {
     int* flag; hipStream_t stream; bool open;
 };
 bool gemm_fp16_enabled();
+bool gemm_limb_chain_ok();      // inside a guard scope on the default tile: producers may emit / consumers may take limb images
 bool gemm_split_enabled();        // a split (limb) GEMM loop is the active variant: the fused spline epilogue is available
 int* gemm_fp16_flag();         // the open scope's device flag of the calling thread, or null
 template <class F>

@@ -425,6 +425,7 @@ struct FlowWs {
     void* kv16;      // K / V limb images of the layer in flight (split-fp16 attention)
     float* ldjp;     // log-det partial slots of the fused spline / pair epilogues, [ldj_slots][P_pad] (ldj_slot_count)
     int ldj_slots;
+    unsigned short* h16;   // fp16 limb image of the last hidden activation feeding the spline parameter GEMM (limb chain)
     int P, P_pad, Pc, Pc_pad, ldkv;
 };
 // Log-det partial slots (rows of FlowWs::ldjp): one per 128-column tile of the fused spline epilogue, two (one per wave column)
@@ -462,13 +463,15 @@ static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t by
     w.cbuf = c.floats(d.nz > 0 ? (size_t)w.P_pad * d.nz_pad : 1);
     w.ldj_slots = ldj_slot_count(f);
     w.ldjp = c.floats(std::max<size_t>((size_t)w.ldj_slots * w.P_pad, 1));
+    w.h16 = (unsigned short*)c.bytes(f.cfg.flow_type == FC_FLOW_SPLINE ? (size_t)w.P_pad * std::max(d.H_pad, 32) * 4 : 16);
     w.kv16 = c.bytes(f.n_attn > 0 ? std::max<size_t>(attention_limb_ws_bytes(w.Pc_pad, d.I_pad), 16) : 16);
     if (need) *need = c.off + 256;
     return w;
 }
 
-static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_segs, const float* rowscal, FlowWs& w, int act, hipStream_t s) {
-    return run_mlp_hidden_generic(m, in_segs, rowscal, act, w.h, std::max(f.d.H_pad, 32), w.P_pad, s, w.P);
+static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_segs, const float* rowscal, FlowWs& w, int act, hipStream_t s,
+                          unsigned short* last_limbs = nullptr) {
+    return run_mlp_hidden_generic(m, in_segs, rowscal, act, w.h, std::max(f.d.H_pad, 32), w.P_pad, s, w.P, last_limbs);
 }
 
 // pre-conditioner: pre-MLP -> LayerNorm -> q -> attention; result in w.a  (models/cif_block.py:14-20 / augmenter.py:15-16)
@@ -511,19 +514,26 @@ static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, c
     } else {
         segs[1] = {w.ctxp, d.E_pad};
     }
-    const int cur = run_mlp_hidden(f, b.net, segs, rowscal, w, c.nonlinearity, s);
-    ASeg a{w.h[cur], ldh};
+    // limb chain: the spline parameter GEMM spans 30 column tiles that would each re-split the same fp32 rows into fp16 limbs; the
+    // layer before it writes its output once as the limb image instead (GemmEpi::C16) and the parameter GEMM copies it (A16)
+    const bool fused_spline = c.flow_type == FC_FLOW_SPLINE && !inverse && gemm_split_enabled() && b.net.out_layer.W3 != nullptr;
+    const PackedLinear& last_hidden = b.net.mid.empty() ? b.net.in_layer : b.net.mid.back();
+    const bool chain = fused_spline && gemm_limb_chain_ok() && b.net.out_layer.W2 != nullptr && last_hidden.W2 != nullptr &&
+                       last_hidden.N_pad == b.net.out_layer.K_pad && last_hidden.N_pad > 64 && b.net.out_layer.nseg == 1;
+    const int cur = run_mlp_hidden(f, b.net, segs, rowscal, w, c.nonlinearity, s, chain ? w.h16 : nullptr);
+    ASeg a{chain ? w.h[0] : w.h[cur], ldh};
     if (c.flow_type == FC_FLOW_AFFINE) {
         GemmEpi e{};
         e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = d.d1_pad; e.d2 = d.d2; e.scale_fn = c.affine_scale_fn;
         e.logprob = logprob; e.rows_valid = w.P; e.inverse = inverse;
         if (!inverse) { e.ldj_part = w.ldjp; e.ldj_pitch = (size_t)w.P_pad; }
         launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_AFFINE, s);
-    } else if (c.flow_type == FC_FLOW_SPLINE && !inverse && gemm_split_enabled() && b.net.out_layer.W3 != nullptr) {
+    } else if (fused_spline) {
         // forward: the parameter GEMM evaluates the splines in its epilogue; only per-tile log-det partials leave the kernel
         GemmEpi e{};
         e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = d.d1_pad; e.d2 = d.d2; e.spline_K = c.num_bins_spline; e.rows_valid = w.P;
         e.ldj_part = w.ldjp; e.ldj_pitch = (size_t)w.P_pad;
+        if (chain) e.A16 = w.h16;
         launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_SPLINE, s);       // log-dets accumulate in w.ldjp; flow_forward reduces them once
     } else {
         GemmEpi e{};

@@ -163,6 +163,7 @@ void gemm_f32_kernel(const GemmParams p) {
         // max-reduced and a launch that met one >= 65504 raises *p.ovf; the entry point then repeats the whole call with the
         // bf16 limbs (unbounded range).  Weights with such entries never get an fp16 image (PackedLinear.W2 == nullptr).
         constexpr bool F16 = VAR >= 5;
+        constexpr bool ALIMB = VAR == 7;                           // A arrives as the fp16 limb image its producer wrote (e.A16): plain copy
         constexpr int KS = 16;                                      // k extent of one LDS stage (32 with one-deep prefetch measured 13 % slower)
         constexpr int KSUB = KS / 16, U = 32 / KS;
         constexpr int NL = F16 ? 2 : 3;                             // limbs
@@ -185,6 +186,9 @@ void gemm_f32_kernel(const GemmParams p) {
         // two register sets: the tile loaded in iteration kt is only converted/stored in iteration kt+1, so a global load has a
         // whole iteration (the MFMAs of the other resident waves included) to land before anything waits for it
         float4 ra3_0[A3], ra3_1[A3];
+        constexpr int A4N = (BM * CH + NT - 1) / NT;                // 16-byte chunks of the A limb image per thread and stage
+        typedef unsigned int u32xa __attribute__((ext_vector_type(4 * A4N)));
+        u32xa ra4_0, ra4_1;
         typedef unsigned int u32xw __attribute__((ext_vector_type(4 * W3N)));      // whole-vector values: never an alloca, so never scratch
         u32xw rw3_0, rw3_1;
 #define FC_GLOAD3(S_, KT_)                                                                                           \
@@ -195,8 +199,18 @@ void gemm_f32_kernel(const GemmParams p) {
                 kk_ -= U * p.kt[0]; Ap_ = p.A[1]; lda_ = p.lda[1];                                                 \
                 if (kk_ >= U * p.kt[1]) { kk_ -= U * p.kt[1]; Ap_ = p.A[2]; lda_ = p.lda[2]; }                     \
             }                                                                                                      \
-            const float* a_ = Ap_ + (size_t)(m0 + lrow3) * lda_ + kk_ * KS + lc3;                                  \
-            _Pragma("unroll") for (int i = 0; i < A3; ++i) ra3_##S_[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(RPP3 * i) * lda_); \
+            if constexpr (ALIMB) {                                                                                 \
+                _Pragma("unroll") for (int i = 0; i < A4N; ++i) {                                                  \
+                    int c_ = tid + NT * i;                                                                         \
+                    c_ = c_ < BM * CH ? c_ : BM * CH - 1;                                                          \
+                    const int slot_ = c_ / CH, part_ = c_ - slot_ * CH, row_ = FC_WROW(slot_);                     \
+                    const uint4 t_ = *reinterpret_cast<const uint4*>(e.A16 + ((size_t)(m0 + row_) * KT16 + (KT_)) * (NL * 16) + part_ * 8); \
+                    ra4_##S_[4 * i] = t_.x; ra4_##S_[4 * i + 1] = t_.y; ra4_##S_[4 * i + 2] = t_.z; ra4_##S_[4 * i + 3] = t_.w; \
+                }                                                                                                  \
+            } else {                                                                                               \
+                const float* a_ = Ap_ + (size_t)(m0 + lrow3) * lda_ + kk_ * KS + lc3;                              \
+                _Pragma("unroll") for (int i = 0; i < A3; ++i) ra3_##S_[i] = *reinterpret_cast<const float4*>(a_ + (size_t)(RPP3 * i) * lda_); \
+            }                                                                                                      \
             _Pragma("unroll") for (int i = 0; i < W3N; ++i) {                                                      \
                 int c_ = tid + NT * i;                                                                             \
                 c_ = c_ < BN * CH ? c_ : BN * CH - 1;     /* unconditional load (a guarded one sends the staging registers through scratch) */ \
@@ -208,8 +222,16 @@ void gemm_f32_kernel(const GemmParams p) {
         }
 #define FC_LSTORE3(S_, ST_)                                                                                          \
         {                                                                                                          \
+            if constexpr (ALIMB) {                                                                                 \
+                _Pragma("unroll") for (int i = 0; i < A4N; ++i) {                                                  \
+                    const int c_ = tid + NT * i, slot_ = c_ / CH, part_ = c_ - slot_ * CH, row_ = FC_WROW(slot_);  \
+                    if (BM * CH % NT == 0 || c_ < BM * CH)                                                         \
+                        *reinterpret_cast<uint4*>(smc + (ST_) * STAGE3 + row_ * ROWB + part_ * 16) =               \
+                            make_uint4(ra4_##S_[4 * i], ra4_##S_[4 * i + 1], ra4_##S_[4 * i + 2], ra4_##S_[4 * i + 3]); \
+                }                                                                                                  \
+            }                                                                                                      \
             char* sa_ = smc + (ST_) * STAGE3 + lrow3 * ROWB + (tid % TPR) * 8;                                      \
-            _Pragma("unroll") for (int i = 0; i < A3; ++i) {                                                       \
+            _Pragma("unroll") for (int i = 0; i < (ALIMB ? 0 : A3); ++i) {                                         \
                 const float x_[4] = {ra3_##S_[i].x, ra3_##S_[i].y, ra3_##S_[i].z, ra3_##S_[i].w};                  \
                 if constexpr (F16) {                                                                               \
                     f16x4 h_, l_;                                                                                  \
@@ -390,6 +412,7 @@ void gemm_f32_kernel(const GemmParams p) {
     // ------------------------------------------------------------------ epilogues
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15
     if constexpr (EPI == EPI_LINEAR) {
+        float omax = 0.f;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             if (j < nvalid) {
@@ -399,11 +422,26 @@ void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        e.C[(size_t)row * e.ldc + col] = act_apply(acc[i][j][r], e.act);
+                        const float v = act_apply(acc[i][j][r], e.act);
+                        if (e.C) e.C[(size_t)row * e.ldc + col] = v;
+                        if (e.C16) {
+                            // the output ALSO / ONLY as the fp16 limb image a following split-fp16 GEMM copies (its 30 column tiles
+                            // would each re-split the same rows): lanes (c, c+1) pair their halves, one 32-bit store per lane
+                            omax = fmaxf(omax, fabsf(v));
+                            const _Float16 hb = (_Float16)v;
+                            const _Float16 lb = (_Float16)((v - (float)hb) * 2048.0f);
+                            const unsigned hu = __builtin_bit_cast(unsigned short, hb), lu = __builtin_bit_cast(unsigned short, lb);
+                            const unsigned mine = (li & 1) ? lu : hu, give = (li & 1) ? hu : lu;
+                            const unsigned got = __shfl_xor(give, 1, 64);
+                            const unsigned word = (li & 1) ? (got | (mine << 16)) : (mine | (got << 16));
+                            const int c0 = col & ~1;
+                            *reinterpret_cast<unsigned*>(e.C16 + ((size_t)row * (p.N_pad >> 4) + (c0 >> 4)) * 32 + ((li & 1) ? 16 : 0) + (c0 & 15)) = word;
+                        }
                     }
                 }
             }
         }
+        if (omax >= 65504.0f) atomicOr(p.ovf, 1);                 // (omax stays 0 without a limb-image output)
     } else if constexpr (EPI == EPI_SPLINE) {
         // ---- fused rational-quadratic spline coupling (forward).  The parameter layer's columns are laid out so that this
         //      128-column tile holds all 3K+1 parameters of DPT transformed dims (spline.h): the tile goes through LDS (the
@@ -513,12 +551,13 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_fused_spline = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_fused_spline = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
 
 bool gemm_fp16_enabled() { return g_gemm_variant == 5; }
+bool gemm_limb_chain_ok() { return g_gemm_variant == 5 && t_fp16_flag != nullptr && g_gemm_bigtile == 3 && g_fused_spline && g_limb_chain; }
 bool gemm_split_enabled() { return (g_gemm_variant == 5 || g_gemm_variant == 3) && g_fused_spline; }
 int* gemm_fp16_flag() { return g_gemm_variant == 5 ? t_fp16_flag : nullptr; }
 long gemm_fp16_fallbacks() { return g_fp16_fallbacks.load(); }
@@ -539,7 +578,7 @@ bool Fp16Guard::overflowed() {
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds_main = VAR == 5 ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds_main = (VAR == 5 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
     constexpr size_t lds_epi = EPI == EPI_SPLINE ? ((size_t)BM * (BN + 1) + (size_t)BM * 9) * sizeof(float) : 0;   // tile + <= 9 dims of log-dets
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
@@ -585,7 +624,9 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     const bool split = (g_gemm_variant == 3 || g_gemm_variant == 5) && L.W3 != nullptr;
     const bool f16 = g_gemm_variant == 5 && L.W2 != nullptr && t_fp16_flag != nullptr;
     if (epi_kind == EPI_LINEAR) {
-        if (!e.C || e.ldc < L.N_pad) throw Error(FC_ERR_INVALID, "launch_gemm: output pitch smaller than N_pad");
+        if ((!e.C && !e.C16) || (e.C && e.ldc < L.N_pad)) throw Error(FC_ERR_INVALID, "launch_gemm: output pitch smaller than N_pad");
+        if (e.C16 && !(f16 && g_gemm_bigtile == 3 && L.N_pad > 64 && L.N_pad % 16 == 0))
+            throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: limb-image output exists on the eight-wave split-fp16 tile only");
         if (L.N_pad <= 64) {
             p.nbm = rows_alloc / 128;
             if (f16) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 5>(p, s);
@@ -619,7 +660,11 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         if ((K != 4 && K != 8 && K != 16) || L.N_pad != spline_ncols(e.d2, K) || !e.xbuf || !e.ldj_part || e.ldj_pitch < (size_t)rows_alloc)
             throw Error(FC_ERR_INVALID, "launch_gemm: bad fused-spline arguments (layout of spline.h, per-tile log-det buffer)");
         p.nbm = rows_alloc / 128;
-        if (f16 && g_gemm_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_SPLINE, 5>(p, s);
+        if (f16 && e.A16 && g_gemm_bigtile == 3) {
+            if (L.nseg != 1) throw Error(FC_ERR_INVALID, "launch_gemm: a limb-image A operand must be the only segment");
+            launch_cfg<128, 128, 4, 2, EPI_SPLINE, 7>(p, s);
+        }
+        else if (f16 && g_gemm_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_SPLINE, 5>(p, s);
         else if (f16) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 5>(p, s);
         else launch_cfg<128, 128, 2, 2, EPI_SPLINE, 3>(p, s);
     } else {

@@ -376,9 +376,10 @@ void pack_mlp_mid(DeviceArena& arena, const WeightTable& wt, const std::string& 
     if (w_out.shape.size() != 2 || w_out.shape[1] != out.sizes.back()) throw Error(FC_ERR_SHAPE, prefix + ".out_layer.weight: input width mismatch");
 }
 int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float* rowscal, int act, float* const h[3], int ldh, int rows,
-                           hipStream_t s, int rows_valid) {
+                           hipStream_t s, int rows_valid, unsigned short* last_limbs) {
     GemmEpi e{};
     e.act = act; e.C = h[0]; e.ldc = ldh; e.rowscal = rowscal; e.rows_valid = rows_valid;
+    if (last_limbs && m.mid.empty()) { e.C = nullptr; e.C16 = last_limbs; }
     launch_gemm(m.in_layer, in_segs, rows, e, EPI_LINEAR, s);
     int cur = 0, keep = -1;
     for (size_t i = 0; i < m.mid.size(); ++i) {
@@ -388,11 +389,12 @@ int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float*
         GemmEpi g{};
         g.act = act; g.C = h[nxt]; g.ldc = ldh; g.rows_valid = rows_valid;
         if (i % 2 == 1) { g.residual = h[keep]; g.ldr = ldh; }
+        if (last_limbs && i + 1 == m.mid.size()) { g.C = nullptr; g.C16 = last_limbs; }
         ASeg a{h[cur], ldh};
         launch_gemm(m.mid[i], &a, rows, g, EPI_LINEAR, s);
         cur = nxt;
     }
-    return cur;
+    return last_limbs ? -1 : cur;
 }
 int max_hidden_pad(const PackedMLP& m) {
     int mx = 0;

@@ -51,8 +51,9 @@ int max_hidden_pad(const PackedMLP& m);
 
 // Runs in_layer + hidden layers of one reference MLP (models/nets.py:19-30: act(in); even hidden layer i: keep = x, x = act(W x);
 // odd: x = act(keep + W x)) over three rotating activation buffers h[0..2] of pitch ldh; returns the buffer index holding the
-// last hidden activation (the caller applies out_layer with the epilogue it needs).
+// last hidden activation (the caller applies out_layer with the epilogue it needs).  With `last_limbs` the LAST hidden layer writes its
+// output only as an fp16 limb image (GemmEpi::C16, pitch = its N_pad) and -1 is returned.
 int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float* rowscal, int act, float* const h[3], int ldh, int rows,
-                           hipStream_t s, int rows_valid = 0);
+                           hipStream_t s, int rows_valid = 0, unsigned short* last_limbs = nullptr);
 
 }  // namespace fc

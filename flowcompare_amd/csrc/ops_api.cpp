@@ -23,7 +23,7 @@ struct TmpBuf {
     return FC_OK;
 
 namespace fc { long gemm_fp16_fallbacks(); }
-namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused; }
+namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain; }
 
 extern "C" {
 
@@ -35,6 +35,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 5) fc::g_attn_fp16 = value;
     else if (key == 7) fc::g_fused_spline = value;
     else if (key == 8) fc::g_premlp_fused = value;
+    else if (key == 9) fc::g_limb_chain = value;
     else return FC_ERR_INVALID;
     return FC_OK;
 }
