@@ -6,37 +6,33 @@
 
 namespace fc {
 
-// erf for the exact-GELU epilogue.  Own piecewise fit (profiles/micro/fit_erf.py): |x| <= 0.95: x * P5(x^2); 0.95 < |x| < 4:
-// 1 - exp(P8(|x|)) (P8 fits log erfc); |x| >= 4: +-1.  Max abs error vs fp64 erf 1.5e-7 (about one fp32 ulp of the result),
-// branch-light (both arms are short fma chains) where ocml's erff costs several times more VALU issue in the epilogue.
-__device__ __forceinline__ float fc_erf(float x) {
-    const float t = fabsf(x);
-    const float s = x * x;
-    float r = -0.0005881639663130045f;
-    r = fmaf(r, s, 0.004971958696842194f);
-    r = fmaf(r, s, -0.026752419769763947f);
-    r = fmaf(r, s, 0.11281437426805496f);
-    r = fmaf(r, s, -0.3761245906352997f);
-    r = fmaf(r, s, 1.1283791065216064f);
-    const float small = r * x;
-    float q = 1.6150449937413214e-06f;
-    q = fmaf(q, t, -4.561102105071768e-05f);
-    q = fmaf(q, t, 0.0005929505568929017f);
-    q = fmaf(q, t, -0.00474111782386899f);
-    q = fmaf(q, t, 0.026367414742708206f);
-    q = fmaf(q, t, -0.10998330265283585f);
-    q = fmaf(q, t, -0.6319313645362854f);
-    q = fmaf(q, t, -1.1301703453063965f);
-    q = fmaf(q, t, 0.00030417676316574216f);
-    float big = 1.0f - __expf(q);
-    big = t >= 4.0f ? 1.0f : big;
-    big = copysignf(big, x);
-    return t <= 0.95f ? small : big;
+// Exact (erf) GELU in one branch-free chain: gelu(v) = v Phi(v), Phi(-|v|) = erfc(u)/2 with u = |v|/sqrt(2), and
+// log2 erfc(u) = -u^2 log2(e) + log2 erfcx(u), where log2 erfcx is smooth and slowly varying (0 ... -3.3 on [0, 5.2]) and is fitted
+// by a degree-11 polynomial (Chebyshev fit, profiles/micro/fit_gelu.py).  22 VALU instructions instead of the 28 of the two-branch erf fit it replaced -- the GEMM epilogues and the fused pre-attention kernel are VALU-bound (PMC: 8-12 VALU instructions per MFMA).
+// fp32 accuracy against fp64: |error| <= 2.4e-7 (half an ulp of v at |v| ~ 5), 9.8e-8 relative to max(1, |v|), and 5e-6 RELATIVE
+// in the negative tail, where the two-branch form lost all relative accuracy (1 - (1 - e^q)).
+__device__ __forceinline__ float fc_gelu(float v) {
+    const float u = fminf(fabsf(v) * 0.70710678118654752440f, 5.2f);
+    float g = 3.599303965984291e-08f;
+    g = fmaf(g, u, -1.1551159104783437e-06f);
+    g = fmaf(g, u, 1.6193846022360958e-05f);
+    g = fmaf(g, u, -0.00012855215754825622f);
+    g = fmaf(g, u, 0.0006109004025347531f);
+    g = fmaf(g, u, -0.0014898879453539848f);
+    g = fmaf(g, u, -0.00129302020650357f);
+    g = fmaf(g, u, 0.02910642884671688f);
+    g = fmaf(g, u, -0.14908140897750854f);
+    g = fmaf(g, u, 0.5244691371917725f);
+    g = fmaf(g, u, -1.627930760383606f);
+    g = fmaf(g, u, 4.18458824924528e-07f);
+    const float e = __builtin_amdgcn_exp2f(fmaf(-1.4426950408889634f * u, u, g));      // erfc(u)
+    const float h = (0.5f * v) * e;                                                   // v Phi(-|v|), signed like v
+    return v > 0.f ? v - h : h;
 }
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     switch (act) {
-        case FC_ACT_GELU: return 0.5f * v * (1.0f + fc_erf(v * 0.70710678118654752440f));
+        case FC_ACT_GELU: return fc_gelu(v);
         case FC_ACT_RELU: return v > 0.f ? v : 0.f;
         case FC_ACT_ELU: return v > 0.f ? v : expm1f(v);
         case FC_ACT_LRELU02: return v > 0.f ? v : 0.2f * v;
