@@ -237,7 +237,9 @@ __global__ __launch_bounds__(PM_NT) __attribute__((amdgpu_waves_per_eu(2))) void
     if (amax >= 65504.0f) atomicOr(p.ovf, 1);
 }
 
-int g_premlp_fused = 1;       // tuning knob (fc_debug_set 8)
+int g_premlp_fused = 0;       // tuning knob (fc_debug_set 8).  OFF by default: this kernel beat the six launches it replaces by 8 % when it was
+                              // written, but the eight-wave GEMM tile and the cheaper GELU then made the separate kernels 2 % faster
+                              // end to end (one 64-row workgroup per CU re-streams every layer's weights from L2: 16 % MFMA busy)
 
 static bool premlp_layer_ok(const PackedLinear& L, int n, int kmax) {
     return L.W2 != nullptr && L.bias != nullptr && L.nseg == 1 && L.N_pad == n && L.n_true == n && L.K_pad % 32 == 0 && L.K_pad <= kmax &&
