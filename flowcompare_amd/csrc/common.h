@@ -103,7 +103,7 @@ inline int gemm_n_alloc(int N_pad) {
 // A operand segment: rows x seg_k floats starting at ptr with row pitch lda
 struct ASeg { const float* ptr; int lda; };
 
-enum Epilogue { EPI_LINEAR = 0, EPI_AFFINE = 1, EPI_AUGMENT = 2, EPI_SLICE = 3, EPI_SPLINE = 4 };
+enum Epilogue { EPI_LINEAR = 0, EPI_AFFINE = 1, EPI_AUGMENT = 2, EPI_SLICE = 3, EPI_SPLINE = 4, EPI_LNQ = 5 };
 
 struct GemmEpi {
     // EPI_LINEAR
@@ -129,6 +129,9 @@ struct GemmEpi {
     const float* val = nullptr; int ldval = 0;             // SLICE: values whose log N(.; mu, sigma) is ADDED to logprob
     const float* val_shift = nullptr; const float* val_scale = nullptr;   // SLICE: v = (val - shift) * scale ; AUGMENT(+inverse): z = z / scale + shift
     int rows_valid = 0;        // rows that exist in user-visible outputs
+    // EPI_LNQ (LayerNorm folded through a linear layer, flow_engine.cpp build_lnq): columns [0, d2) are the centred layer's outputs --
+    // only their per-row sums of squares leave the kernel, ldj_part[(64-column block) * ldj_pitch + row] = sum -- and columns
+    // [d2, d2 + 64) go to C (pitch ldc) as the un-normalised q projection
     // EPI_SPLINE (forward rational-quadratic spline coupling evaluated by the workgroup that produced the parameters; uses
     // xbuf / ldx / x2_col0 / d2 / rows_valid above): y2 overwrites x2, per-tile log-dets are ACCUMULATED into ldj_part[tile * ldj_pitch + row]
     // (the caller zeroes the buffer before the first layer and reduces it over the tiles once after the last, launch_ldj_reduce)
@@ -149,7 +152,9 @@ struct Fp16Guard {
     int* flag; hipStream_t stream; bool open;
 };
 bool gemm_fp16_enabled();
-bool gemm_limb_chain_ok();      // inside a guard scope on the default tile: producers may emit / consumers may take limb images
+bool gemm_limb_chain_ok();
+bool gemm_lnq_ok();             // the LayerNorm -> q fold (EPI_LNQ) can run: guard scope open, default tile
+void launch_lnq_finalize(float* q, int ldq, const float* sumsq, int nslots, size_t pitch, int width, const float* q_bias, int rows, hipStream_t s);      // inside a guard scope on the default tile: producers may emit / consumers may take limb images
 bool gemm_split_enabled();        // a split (limb) GEMM loop is the active variant: the fused spline epilogue is available
 int* gemm_fp16_flag();         // the open scope's device flag of the calling thread, or null
 template <class F>

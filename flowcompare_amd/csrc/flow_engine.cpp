@@ -22,6 +22,13 @@ namespace fc {
 
 struct AttnPack {
     PackedLinear q;      // LN-folded, pre-scaled q projection  [I_pad][A_in_pad]
+    MatD q_w;            // the same folded matrix / bias on the host (double), for the LayerNorm -> q fold below
+    VecD q_b;
+    // LayerNorm folded THROUGH the (activation-free) pre-MLP out_layer: rows [0, A_in) = mean-centred out_layer (its outputs are only
+    // squared and summed per row), rows [A_in, A_in + I_pad) = q projection of the centred outputs; q = q_unnorm * rstd + q_bias
+    PackedLinear lnq;
+    float* q_bias = nullptr;
+    bool has_lnq = false;
     MatD lin_w;          // [attn_dim][I]  (folded into the consumer's in_layer)
     VecD lin_b;
     int kv_col = 0;      // column of this layer's [K | V] block inside the kv buffer
@@ -105,6 +112,8 @@ static void build_attn(fc_flow& f, const WeightTable& wt, const std::string& p, 
             wq.at(i, k) *= c * gamma[k];
         }
     out.q = pack_linear(f.arena, wq, bq, {}, map_prefix(I, d.I_pad), map_prefix(A_in, d.A_in_pad), {d.A_in_pad});
+    out.q_w = wq;
+    out.q_b = bq;
     const HostTensor& wkv_t = wt.get(p + ".fn.attention.to_kv.weight", {2 * I, d.E});
     MatD wkv = mat_from(wkv_t);                 // rows [0,I) = K, [I,2I) = V  (chunk(2, dim=-1))
     MatD blk(2 * d.I_pad, d.E);
@@ -116,6 +125,45 @@ static void build_attn(fc_flow& f, const WeightTable& wt, const std::string& p, 
     if (wl.shape.size() != 2 || wl.shape[1] != I) throw Error(FC_ERR_SHAPE, p + ".fn.lin.weight: expected [attn_dim, inner]");
     out.lin_w = mat_from(wl);
     out.lin_b = vec_from(wt.get(p + ".fn.lin.bias", {wl.shape[0]}));
+}
+
+// LayerNorm -> q fold (see AttnPack::lnq).  h = W3 a + b3 has no activation, so its centred form h_c = h - mean(h) is linear in a:
+// W3c = W3 - 1 (1^T W3)/A_in, b3c = b3 - mean(b3).  LayerNorm(h) = h_c / sigma (gamma, beta live in the q projection), hence
+// q = Wq' h_c / sigma + bq' = (Wq' W3c a + Wq' b3c) / sigma + bq' with sigma^2 = mean(h_c^2) + eps.  One GEMM with N = A_in + I_pad
+// columns yields h_c (only squared and summed per row in the epilogue, never stored) and q_unnorm; lnq_finalize_kernel applies
+// rstd and bq'.  Replaces out_layer's store, the LayerNorm pass and the q projection GEMM.
+static void build_lnq(fc_flow& f, const WeightTable& wt, const std::string& out_prefix, AttnPack& at) {
+    const Dims& d = f.d;
+    const HostTensor& w_t = wt.get(out_prefix + ".weight");
+    const MatD w3 = mat_from(w_t);
+    const int A = w3.rows, K = w3.cols;
+    if (A != d.A_in || d.A_in != d.A_in_pad || d.A_in % 64 != 0 || d.I_pad != 64 || K % 32 != 0) return;     // shapes the fused epilogue handles
+    const VecD b3 = vec_from(wt.get(out_prefix + ".bias", {A}));
+    MatD m(A + d.I_pad, K);
+    VecD bias(A + d.I_pad, 0.0);
+    double bmean = 0.0;
+    for (int o = 0; o < A; ++o) bmean += b3[o] / A;
+    for (int k = 0; k < K; ++k) {
+        double cm = 0.0;
+        for (int o = 0; o < A; ++o) cm += w3.at(o, k) / A;
+        for (int o = 0; o < A; ++o) m.at(o, k) = w3.at(o, k) - cm;
+    }
+    for (int o = 0; o < A; ++o) bias[o] = b3[o] - bmean;
+    for (int i = 0; i < at.q_w.rows; ++i) {
+        for (int k = 0; k < K; ++k) {
+            double acc = 0.0;
+            for (int o = 0; o < A; ++o) acc += at.q_w.at(i, o) * m.at(o, k);
+            m.at(A + i, k) = acc;
+        }
+        double acc = 0.0;
+        for (int o = 0; o < A; ++o) acc += at.q_w.at(i, o) * bias[o];
+        bias[A + i] = acc;
+    }
+    at.lnq = pack_linear(f.arena, m, bias, {}, map_prefix(A + d.I_pad, A + d.I_pad), map_prefix(K, K), {K});
+    std::vector<float> qb(d.I_pad, 0.f);
+    for (int i = 0; i < at.q_w.rows; ++i) qb[i] = (float)at.q_b[i];
+    at.q_bias = f.arena.upload(qb);
+    at.has_lnq = at.lnq.W2 != nullptr;
 }
 
 // in_layer over cat(first(n_first), extra(X), ctxvec(C)) -> packed [first_pad | second_pad] + rank-1 extra column.
@@ -363,6 +411,7 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
         f.aug_pre.in_layer = build_plain(f, wt, p + ".pre_attn_mlp.in_layer", d.Din, 32);
         f.aug_pre.out_layer = build_plain(f, wt, p + ".pre_attn_mlp.out_layer", f.aug_pre.sizes.back(), round_up(f.aug_pre.sizes.back(), 32));
         if (f.aug_pre.out_layer.N_pad != d.A_in_pad) throw Error(FC_ERR_SHAPE, "pre_attn_mlp output width != attn_input_dim");
+        build_lnq(f, wt, p + ".pre_attn_mlp.out_layer", f.aug_attn);
         const std::string pn = p + ".augment.noise_dist.net";
         pack_mlp_mid(f.arena, wt, pn, f.aug_net);
         f.aug_net.in_layer = build_in_layer(f, wt, pn, d.Din, 32, &f.aug_attn);
@@ -390,6 +439,7 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
             b.pre.in_layer = build_plain(f, wt, pp + ".in_layer", d.d1, d.d1_pad);
             b.pre.out_layer = build_plain(f, wt, pp + ".out_layer", b.pre.sizes.back(), round_up(b.pre.sizes.back(), 32));
             if (b.pre.out_layer.N_pad != d.A_in_pad) throw Error(FC_ERR_SHAPE, "pre_attention_mlp output width != attn_input_dim");
+            build_lnq(f, wt, pp + ".out_layer", b.attn);
             d.H_pad = std::max({d.H_pad, max_hidden_pad(b.pre), d.A_in_pad});
         }
         const std::string pn = p + ".transform.nn";
@@ -425,6 +475,7 @@ struct FlowWs {
     void* kv16;      // K / V limb images of the layer in flight (split-fp16 attention)
     float* ldjp;     // log-det partial slots of the fused spline / pair epilogues, [ldj_slots][P_pad] (ldj_slot_count)
     int ldj_slots;
+    float* lnss;           // [A_in / 64][P_pad] per-row sums of squares of the centred pre-MLP output (LayerNorm -> q fold)
     unsigned short* h16;   // fp16 limb image of the last hidden activation feeding the spline parameter GEMM (limb chain)
     int P, P_pad, Pc, Pc_pad, ldkv;
 };
@@ -464,6 +515,7 @@ static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t by
     w.ldj_slots = ldj_slot_count(f);
     w.ldjp = c.floats(std::max<size_t>((size_t)w.ldj_slots * w.P_pad, 1));
     w.h16 = (unsigned short*)c.bytes(f.cfg.flow_type == FC_FLOW_SPLINE ? (size_t)w.P_pad * std::max(d.H_pad, 32) * 4 : 16);
+    w.lnss = c.floats(f.n_attn > 0 ? (size_t)(std::max(d.A_in, 64) / 64) * w.P_pad : 1);
     w.kv16 = c.bytes(f.n_attn > 0 ? std::max<size_t>(attention_limb_ws_bytes(w.Pc_pad, d.I_pad), 16) : 16);
     if (need) *need = c.off + 256;
     return w;
@@ -484,6 +536,17 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
         launch_premlp(in.ptr, in.lda, pre.in_layer, pre.mid, pre.out_layer, at.q, act, w.q, d.I_pad, w.P_pad, w.P, s);
     } else {
         const int cur = run_mlp_hidden(f, pre, &in, nullptr, w, act, s);
+        if (at.has_lnq && gemm_lnq_ok()) {
+            // out_layer, LayerNorm and the q projection as ONE GEMM (AttnPack::lnq) + a 16 MB finalize pass
+            GemmEpi e{};
+            e.C = w.q; e.ldc = d.I_pad; e.d2 = d.A_in; e.ldj_part = w.lnss; e.ldj_pitch = (size_t)w.P_pad; e.rows_valid = w.P;
+            ASeg a{w.h[cur], ldh};
+            launch_gemm(at.lnq, &a, w.P_pad, e, EPI_LNQ, s);
+            launch_lnq_finalize(w.q, d.I_pad, w.lnss, d.A_in / 64, (size_t)w.P_pad, d.A_in, at.q_bias, w.P, s);
+            launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad,
+                             w.kv16, s);
+            return;
+        }
         int o = 0;
         while (o == cur) ++o;
         GemmEpi e{};

@@ -105,7 +105,7 @@ void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         float bv = 0.f;
-        if constexpr (EPI == EPI_LINEAR || EPI == EPI_SPLINE) bv = p.bias ? p.bias[wave_n0 + j * 32 + li] : 0.f;
+        if constexpr (EPI == EPI_LINEAR || EPI == EPI_SPLINE || EPI == EPI_LNQ) bv = p.bias ? p.bias[wave_n0 + j * 32 + li] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -442,6 +442,24 @@ void gemm_f32_kernel(const GemmParams p) {
             }
         }
         if (omax >= 65504.0f) atomicOr(p.ovf, 1);                 // (omax stays 0 without a limb-image output)
+    } else if constexpr (EPI == EPI_LNQ) {
+        // ---- LayerNorm folded through the layer (common.h): a wave's 64 columns are either hidden columns (sum of squares per row
+        //      into the block's slot) or the 64 q columns (stored un-normalised)
+        static_assert(TN == 2 && TM == 1, "LNQ epilogue is written for the eight-wave 128x128 tile");
+        if (wave_n0 < e.d2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = acc[0][0][r] * acc[0][0][r] + acc[0][1][r] * acc[0][1][r];
+                t = half_wave_sum(t);
+                if (li == 0) e.ldj_part[(size_t)(wave_n0 >> 6) * e.ldj_pitch + wave_m0 + (r & 3) + 8 * (r >> 2) + 4 * lh] = t;
+            }
+        } else if (wave_n0 < e.d2 + 64) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    e.C[(size_t)(wave_m0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * e.ldc + (wave_n0 - e.d2) + j * 32 + li] = acc[0][j][r];
+        }
     } else if constexpr (EPI == EPI_SPLINE) {
         // ---- fused rational-quadratic spline coupling (forward).  The parameter layer's columns are laid out so that this
         //      128-column tile holds all 3K+1 parameters of DPT transformed dims (spline.h): the tile goes through LDS (the
@@ -551,12 +569,13 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_fused_spline = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_lnq_fold = 1, g_fused_spline = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
 
 bool gemm_fp16_enabled() { return g_gemm_variant == 5; }
+bool gemm_lnq_ok() { return g_gemm_variant == 5 && t_fp16_flag != nullptr && g_gemm_bigtile == 3 && g_lnq_fold; }
 bool gemm_limb_chain_ok() { return g_gemm_variant == 5 && t_fp16_flag != nullptr && g_gemm_bigtile == 3 && g_fused_spline && g_limb_chain; }
 bool gemm_split_enabled() { return (g_gemm_variant == 5 || g_gemm_variant == 3) && g_fused_spline; }
 int* gemm_fp16_flag() { return g_gemm_variant == 5 ? t_fp16_flag : nullptr; }
@@ -613,7 +632,7 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         kt += p.kt[i];
     }
     if (kt * 32 != L.K_pad) throw Error(FC_ERR_INVALID, "launch_gemm: segment widths do not add up to K_pad");
-    if (L.n_alloc < round_up(L.N_pad, gemm_bn(L.N_pad, epi_kind != EPI_LINEAR && epi_kind != EPI_SPLINE)) || L.n_alloc < round_up(L.N_pad, 128))
+    if (L.n_alloc < round_up(L.N_pad, gemm_bn(L.N_pad, epi_kind != EPI_LINEAR && epi_kind != EPI_SPLINE && epi_kind != EPI_LNQ)) || L.n_alloc < round_up(L.N_pad, 128))
         throw Error(FC_ERR_INVALID, "launch_gemm: W is not zero-padded to the column-tile grid (PackedLinear.n_alloc)");
     p.KT = kt;
     GemmEpi e = e_in;
@@ -654,6 +673,12 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             p.nbm = rows_alloc / 128;
             if (split) launch_cfg<128, 320, 4, 1, EPI_LINEAR, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_LINEAR>(p, s);
         }
+    } else if (epi_kind == EPI_LNQ) {
+        if (!(f16 && g_gemm_bigtile == 3)) throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: the LayerNorm -> q fold runs on the eight-wave split-fp16 tile only");
+        if (!e.C || !e.ldj_part || e.d2 % 64 != 0 || L.N_pad != e.d2 + 64 || e.ldc < 64 || e.ldj_pitch < (size_t)rows_alloc || !L.bias)
+            throw Error(FC_ERR_INVALID, "launch_gemm: bad LayerNorm -> q fold arguments");
+        p.nbm = rows_alloc / 128;
+        launch_cfg<128, 128, 4, 2, EPI_LNQ, 5>(p, s);
     } else if (epi_kind == EPI_SPLINE) {
         const int K = e.spline_K;
         if (!split) throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: the fused spline epilogue exists for the split GEMM loops only");

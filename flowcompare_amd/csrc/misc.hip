@@ -94,6 +94,23 @@ void launch_layernorm(float* h, int ld, int width, int rows, hipStream_t s) {
     FC_HIP(hipGetLastError());
 }
 
+// q[row, :] = q_unnorm[row, :] * rsqrt(sum_blocks(sumsq[b][row]) / width + 1e-5) + q_bias   (LayerNorm -> q fold, common.h EPI_LNQ)
+__global__ __launch_bounds__(256) void lnq_finalize_kernel(float* __restrict__ q, int ldq, const float* __restrict__ sumsq, int nslots, size_t pitch,
+                                                           float inv_width, const float* __restrict__ q_bias, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float ss = 0.f;
+    for (int b = 0; b < nslots; ++b) ss += sumsq[(size_t)b * pitch + row];
+    const float rstd = 1.0f / sqrtf(ss * inv_width + 1e-5f);
+    float* qr = q + (size_t)row * ldq;
+    qr[lane] = qr[lane] * rstd + q_bias[lane];
+}
+void launch_lnq_finalize(float* q, int ldq, const float* sumsq, int nslots, size_t pitch, int width, const float* q_bias, int rows, hipStream_t s) {
+    ProfScope ps("fc::lnq_finalize_kernel", 0.0, 4.0 * rows * (128.0 + nslots), s);
+    hipLaunchKernelGGL(lnq_finalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, q, ldq, sumsq, nslots, pitch, 1.0f / (float)width, q_bias, rows);
+    FC_HIP(hipGetLastError());
+}
+
 // ---------------------------------------------------------------- base density + latent export
 // logprob[row] += sum_d(-0.5 log 2pi - 0.5 x_d^2) + log_const   (models/distributions.py:192-195)
 // x is in the engine layout [x1 (d1) | pad | x2 (d2) | pad]; z_out (optional) gets the dense [rows, D] latent.
