@@ -21,6 +21,7 @@ namespace fc {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 int g_attn_fp16 = 1;      // tuning knob (fc_debug_set 5): 0 keeps the fp32-input MFMA kernel
+bool attention_fp16_enabled() { return g_attn_fp16 != 0; }
 
 struct AttnParams {
     const float* q; int ldq;
@@ -205,6 +206,8 @@ struct Attn16Params {
     int N, n_stride, M, m_stride;
     float qscale;
     int* ovf;
+    int kv_pitch;                   // row pitch of the k16 / v16 images in 16-byte chunks (DH / 4 for the packed images)
+    int c16;                        // 1: rows are slices of a GEMM's limb-image output ([16 columns: hi 16 | lo' 16] tiles, GemmEpi::C16)
 };
 
 // fp32 K / V columns of the projected context -> limb row images; raises *ovf on |x| >= 65504.
@@ -283,14 +286,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     // ---- staging: plain 16-byte copies of the limb images (whole-vector register values: arrays went through scratch)
     typedef unsigned int u32xs __attribute__((ext_vector_type(4 * NCH)));
     u32xs rk, rv;
-    const uint4* kb = reinterpret_cast<const uint4*>(p.k16) + (size_t)b * p.m_stride * CPR;
-    const uint4* vb = reinterpret_cast<const uint4*>(p.v16) + (size_t)b * p.m_stride * CPR;
+    const uint4* kb = reinterpret_cast<const uint4*>(p.k16) + (size_t)b * p.m_stride * p.kv_pitch;
+    const uint4* vb = reinterpret_cast<const uint4*>(p.v16) + (size_t)b * p.m_stride * p.kv_pitch;
 #define FC_GLOAD(T_)                                                                          \
     _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                         \
         const int c_ = tid + 256 * i, kr_ = c_ / CPR, part_ = c_ - kr_ * CPR;                 \
         int key_ = (T_) * 64 + kr_;                                                           \
         key_ = key_ < p.M ? key_ : p.M - 1; /* clamped rows are masked to -inf below */       \
-        const uint4 a_ = kb[(size_t)key_ * CPR + part_], b_ = vb[(size_t)key_ * CPR + part_];  \
+        /* chunk part_ of the [hi DH | lo' DH] row = limb part_/(CPR/2), columns 8 w .. 8 w + 7; in a C16 slice that is chunk   */ \
+        /* (w >> 1) * 4 + limb * 2 + (w & 1)                                                                                    */ \
+        const int w_ = part_ % (CPR / 2), lb_ = part_ / (CPR / 2);                             \
+        const int sp_ = p.c16 ? (w_ >> 1) * 4 + lb_ * 2 + (w_ & 1) : part_;                    \
+        const uint4 a_ = kb[(size_t)key_ * p.kv_pitch + sp_], b_ = vb[(size_t)key_ * p.kv_pitch + sp_];  \
         rk[4 * i] = a_.x; rk[4 * i + 1] = a_.y; rk[4 * i + 2] = a_.z; rk[4 * i + 3] = a_.w;     \
         rv[4 * i] = b_.x; rv[4 * i + 1] = b_.y; rv[4 * i + 2] = b_.z; rv[4 * i + 3] = b_.w;     \
     }
@@ -459,8 +466,17 @@ static void launch_attn_dh(const AttnParams& p, int B, hipStream_t s) {
 
 static void launch_attention_scaled(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                                     int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, float qscale, void* limb_ws,
-                                    hipStream_t s) {
+                                    hipStream_t s, const unsigned short* k_c16 = nullptr, const unsigned short* v_c16 = nullptr, int c16_pitch = 0) {
     if (B <= 0 || N <= 0 || M <= 0) throw Error(FC_ERR_INVALID, "attention: empty problem");
+    if (k_c16) {
+        // K / V arrive as slices of the projection GEMM's limb-image output: no fp32 K / V, no conversion pass
+        int* flag16 = gemm_fp16_flag();
+        if (!flag16 || dh_pad > 64 || !v_c16 || c16_pitch <= 0 || (ldq % 4) != 0)
+            throw Error(FC_ERR_INVALID, "attention: limb-image K / V need a guard scope, head dim <= 64 and a pitch");
+        Attn16Params p{q, ldq, k_c16, v_c16, out, ldo, N, n_stride_rows, M, m_stride_rows, qscale, flag16, c16_pitch, 1};
+        if (dh_pad == 32) launch_attn16_dh<32>(p, B, s); else launch_attn16_dh<64>(p, B, s);
+        return;
+    }
     if ((ldq | ldk | ldv) % 4 != 0 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15))
         throw Error(FC_ERR_INVALID, "attention: q/k/v must be 16-byte aligned with pitches that are multiples of 4 floats");
     int* flag = gemm_fp16_flag();
@@ -475,7 +491,7 @@ static void launch_attention_scaled(const float* q, int ldq, const float* k, int
             hipLaunchKernelGGL(kv_limbs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, ldk, v, ldv, k16, v16, rows, dh_pad, flag);
             FC_HIP(hipGetLastError());
         }
-        Attn16Params p{q, ldq, k16, v16, out, ldo, N, n_stride_rows, M, m_stride_rows, qscale, flag};
+        Attn16Params p{q, ldq, k16, v16, out, ldo, N, n_stride_rows, M, m_stride_rows, qscale, flag, dh_pad / 4, 0};
         if (dh_pad == 32) launch_attn16_dh<32>(p, B, s); else launch_attn16_dh<64>(p, B, s);
         return;
     }
@@ -493,6 +509,15 @@ size_t attention_limb_ws_bytes(long kv_rows, int dh_pad) { return dh_pad <= 64 ?
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                       int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, void* limb_ws, hipStream_t s) {
     launch_attention_scaled(q, ldq, k, ldk, v, ldv, out, ldo, B, N, n_stride_rows, M, m_stride_rows, dh_pad, 1.0f, limb_ws, s);
+}
+
+// K | V of this layer as columns [col0, col0 + 2 * dh_pad) of a GEMM limb-image output with n_pad columns per row (GemmEpi::C16)
+void launch_attention_c16(const float* q, int ldq, const unsigned short* kv_c16, int n_pad, int col0, float* out, int ldo, int B, int N,
+                          int n_stride_rows, int M, int m_stride_rows, int dh_pad, hipStream_t s) {
+    if (col0 % 16 != 0 || n_pad % 16 != 0 || dh_pad % 16 != 0) throw Error(FC_ERR_INVALID, "attention: limb-image slices must start on 16-column tiles");
+    const unsigned short* kp = kv_c16 + (size_t)(col0 / 16) * 32;
+    const unsigned short* vp = kp + (size_t)(dh_pad / 16) * 32;
+    launch_attention_scaled(q, ldq, nullptr, 4, nullptr, 4, out, ldo, B, N, n_stride_rows, M, m_stride_rows, dh_pad, 1.0f, nullptr, s, kp, vp, n_pad / 4);
 }
 
 void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale,

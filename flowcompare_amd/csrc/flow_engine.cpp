@@ -475,6 +475,7 @@ struct FlowWs {
     void* kv16;      // K / V limb images of the layer in flight (split-fp16 attention)
     float* ldjp;     // log-det partial slots of the fused spline / pair epilogues, [ldj_slots][P_pad] (ldj_slot_count)
     int ldj_slots;
+    bool kv_limbs;         // w.kv holds the K|V projections as the GEMM's fp16 limb image (GemmEpi::C16) instead of fp32
     float* lnss;           // [A_in / 64][P_pad] per-row sums of squares of the centred pre-MLP output (LayerNorm -> q fold)
     unsigned short* h16;   // fp16 limb image of the last hidden activation feeding the spline parameter GEMM (limb chain)
     int P, P_pad, Pc, Pc_pad, ldkv;
@@ -543,8 +544,12 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
             ASeg a{w.h[cur], ldh};
             launch_gemm(at.lnq, &a, w.P_pad, e, EPI_LNQ, s);
             launch_lnq_finalize(w.q, d.I_pad, w.lnss, d.A_in / 64, (size_t)w.P_pad, d.A_in, at.q_bias, w.P, s);
-            launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad,
-                             w.kv16, s);
+            if (w.kv_limbs)
+                launch_attention_c16(w.q, d.I_pad, reinterpret_cast<const unsigned short*>(w.kv), w.ldkv, at.kv_col, w.a, d.I_pad, B, N, N, M, M,
+                                     d.I_pad, s);
+            else
+                launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad,
+                                 w.kv16, s);
             return;
         }
         int o = 0;
@@ -559,7 +564,8 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
         ASeg aq{w.h[o], ldh};
         launch_gemm(at.q, &aq, w.P_pad, eq, EPI_LINEAR, s);
     }
-    launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad, w.kv16, s);
+    if (w.kv_limbs) launch_attention_c16(w.q, d.I_pad, reinterpret_cast<const unsigned short*>(w.kv), w.ldkv, at.kv_col, w.a, d.I_pad, B, N, N, M, M, d.I_pad, s);
+    else launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad, w.kv16, s);
 }
 
 // the conditioned coupling of one block (PreConditionApplier, models/transform.py:47-58), forward or inverse, in place on xc
@@ -647,8 +653,12 @@ static Prep prepare(fc_flow& f, const float* ctx, const float* extra, int B, int
     launch_pack_rows(ctx, d.E, d.E, w.ctxp, d.E_pad, 0, d.E_pad, w.Pc, s);
     if (d.X) { launch_repeat_extra(extra, d.X, w.rowscal, B, N, s); p.rowscal = w.rowscal; }
     if (f.n_attn) {
+        // inside a guard scope the stacked K|V projection writes its output straight as the limb image the split-fp16 attention
+        // stages (same bytes, same buffer): no fp32 K/V, no per-layer conversion pass
+        w.kv_limbs = gemm_limb_chain_ok() && attention_fp16_enabled() && d.I_pad <= 64 && f.kv_all.W2 != nullptr && w.ldkv % 128 == 0 && w.ldkv == f.kv_all.N_pad;
         GemmEpi e{};
-        e.C = w.kv; e.ldc = w.ldkv; e.rows_valid = w.Pc;
+        e.rows_valid = w.Pc;
+        if (w.kv_limbs) e.C16 = reinterpret_cast<unsigned short*>(w.kv); else { e.C = w.kv; e.ldc = w.ldkv; }
         ASeg a{w.ctxp, d.E_pad};
         launch_gemm(f.kv_all, &a, w.Pc_pad, e, EPI_LINEAR, s);
     }
