@@ -97,17 +97,20 @@ void launch_layernorm(float* h, int ld, int width, int rows, hipStream_t s) {
 // q[row, :] = q_unnorm[row, :] * rsqrt(sum_blocks(sumsq[b][row]) / width + 1e-5) + q_bias   (LayerNorm -> q fold, common.h EPI_LNQ)
 __global__ __launch_bounds__(256) void lnq_finalize_kernel(float* __restrict__ q, int ldq, const float* __restrict__ sumsq, int nslots, size_t pitch,
                                                            float inv_width, const float* __restrict__ q_bias, int rows) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;          // 16 threads per row, one float4 of the 64 q columns each
+    const int row = (int)(t >> 4), c4 = ((int)t & 15) * 4;
     if (row >= rows) return;
     float ss = 0.f;
     for (int b = 0; b < nslots; ++b) ss += sumsq[(size_t)b * pitch + row];
     const float rstd = 1.0f / sqrtf(ss * inv_width + 1e-5f);
-    float* qr = q + (size_t)row * ldq;
-    qr[lane] = qr[lane] * rstd + q_bias[lane];
+    float4* qp = reinterpret_cast<float4*>(q + (size_t)row * ldq + c4);
+    const float4 v = *qp, bq = *reinterpret_cast<const float4*>(q_bias + c4);
+    *qp = make_float4(v.x * rstd + bq.x, v.y * rstd + bq.y, v.z * rstd + bq.z, v.w * rstd + bq.w);
 }
 void launch_lnq_finalize(float* q, int ldq, const float* sumsq, int nslots, size_t pitch, int width, const float* q_bias, int rows, hipStream_t s) {
     ProfScope ps("fc::lnq_finalize_kernel", 0.0, 4.0 * rows * (128.0 + nslots), s);
-    hipLaunchKernelGGL(lnq_finalize_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, q, ldq, sumsq, nslots, pitch, 1.0f / (float)width, q_bias, rows);
+    hipLaunchKernelGGL(lnq_finalize_kernel, dim3((unsigned)(((long)rows * 16 + 255) / 256)), dim3(256), 0, s, q, ldq, sumsq, nslots, pitch,
+                       1.0f / (float)width, q_bias, rows);
     FC_HIP(hipGetLastError());
 }
 
