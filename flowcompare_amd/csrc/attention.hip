@@ -206,6 +206,9 @@ struct Attn16Params {
     int N, n_stride, M, m_stride;
     float qscale;
     int* ovf;
+    // optional LayerNorm -> q fold (common.h EPI_LNQ): q holds the UN-normalised projection; the kernel applies
+    // q * rsqrt(sum_b q_sumsq[b][row] * q_inv_width + 1e-5) + q_bias while it loads its query (no separate finalize pass)
+    const float* q_sumsq; int q_slots; size_t q_pitch; float q_inv_width; const float* q_bias;
     int kv_pitch;                   // row pitch of the k16 / v16 images in 16-byte chunks (DH / 4 for the packed images)
     int c16;                        // 1: rows are slices of a GEMM's limb-image output ([16 columns: hi 16 | lo' 16] tiles, GemmEpi::C16)
 };
@@ -260,14 +263,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     {
         int qi = q0 + li;
         qi = qi < p.N ? qi : p.N - 1;
-        const float* qp = p.q + ((size_t)b * p.n_stride + qi) * p.ldq + 8 * lh;
+        const size_t qrow = (size_t)b * p.n_stride + qi;
+        const float* qp = p.q + qrow * p.ldq + 8 * lh;
+        float rstd = 1.0f;
+        if (p.q_sumsq) {
+            float ss = 0.f;
+            for (int sb = 0; sb < p.q_slots; ++sb) ss += p.q_sumsq[(size_t)sb * p.q_pitch + qrow];
+            rstd = 1.0f / sqrtf(ss * p.q_inv_width + 1e-5f);
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * s), t1 = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
             const float xs[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float x = xs[e] * p.qscale;
+                const float bq = p.q_bias ? p.q_bias[16 * s + 8 * lh + e] : 0.f;
+                const float x = (xs[e] * rstd + bq) * p.qscale;
                 amax = fmaxf(amax, fabsf(x));
                 qh[s][e] = (_Float16)x;
                 ql[s][e] = (_Float16)((x - (float)qh[s][e]) * 2048.0f);
@@ -466,14 +477,16 @@ static void launch_attn_dh(const AttnParams& p, int B, hipStream_t s) {
 
 static void launch_attention_scaled(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                                     int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, float qscale, void* limb_ws,
-                                    hipStream_t s, const unsigned short* k_c16 = nullptr, const unsigned short* v_c16 = nullptr, int c16_pitch = 0) {
+                                    hipStream_t s, const unsigned short* k_c16 = nullptr, const unsigned short* v_c16 = nullptr, int c16_pitch = 0,
+                                    const AttnLnq* lnq = nullptr) {
     if (B <= 0 || N <= 0 || M <= 0) throw Error(FC_ERR_INVALID, "attention: empty problem");
     if (k_c16) {
         // K / V arrive as slices of the projection GEMM's limb-image output: no fp32 K / V, no conversion pass
         int* flag16 = gemm_fp16_flag();
         if (!flag16 || dh_pad > 64 || !v_c16 || c16_pitch <= 0 || (ldq % 4) != 0)
             throw Error(FC_ERR_INVALID, "attention: limb-image K / V need a guard scope, head dim <= 64 and a pitch");
-        Attn16Params p{q, ldq, k_c16, v_c16, out, ldo, N, n_stride_rows, M, m_stride_rows, qscale, flag16, c16_pitch, 1};
+        Attn16Params p{q, ldq, k_c16, v_c16, out, ldo, N, n_stride_rows, M, m_stride_rows, qscale, flag16, lnq ? lnq->sumsq : nullptr,
+                       lnq ? lnq->slots : 0, lnq ? lnq->pitch : 0, lnq ? lnq->inv_width : 0.f, lnq ? lnq->bias : nullptr, c16_pitch, 1};
         if (dh_pad == 32) launch_attn16_dh<32>(p, B, s); else launch_attn16_dh<64>(p, B, s);
         return;
     }
@@ -491,7 +504,7 @@ static void launch_attention_scaled(const float* q, int ldq, const float* k, int
             hipLaunchKernelGGL(kv_limbs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, ldk, v, ldv, k16, v16, rows, dh_pad, flag);
             FC_HIP(hipGetLastError());
         }
-        Attn16Params p{q, ldq, k16, v16, out, ldo, N, n_stride_rows, M, m_stride_rows, qscale, flag, dh_pad / 4, 0};
+        Attn16Params p{q, ldq, k16, v16, out, ldo, N, n_stride_rows, M, m_stride_rows, qscale, flag, nullptr, 0, 0, 0.f, nullptr, dh_pad / 4, 0};
         if (dh_pad == 32) launch_attn16_dh<32>(p, B, s); else launch_attn16_dh<64>(p, B, s);
         return;
     }
@@ -513,11 +526,11 @@ void launch_attention(const float* q, int ldq, const float* k, int ldk, const fl
 
 // K | V of this layer as columns [col0, col0 + 2 * dh_pad) of a GEMM limb-image output with n_pad columns per row (GemmEpi::C16)
 void launch_attention_c16(const float* q, int ldq, const unsigned short* kv_c16, int n_pad, int col0, float* out, int ldo, int B, int N,
-                          int n_stride_rows, int M, int m_stride_rows, int dh_pad, hipStream_t s) {
+                          int n_stride_rows, int M, int m_stride_rows, int dh_pad, hipStream_t s, const AttnLnq* lnq) {
     if (col0 % 16 != 0 || n_pad % 16 != 0 || dh_pad % 16 != 0) throw Error(FC_ERR_INVALID, "attention: limb-image slices must start on 16-column tiles");
     const unsigned short* kp = kv_c16 + (size_t)(col0 / 16) * 32;
     const unsigned short* vp = kp + (size_t)(dh_pad / 16) * 32;
-    launch_attention_scaled(q, ldq, nullptr, 4, nullptr, 4, out, ldo, B, N, n_stride_rows, M, m_stride_rows, dh_pad, 1.0f, nullptr, s, kp, vp, n_pad / 4);
+    launch_attention_scaled(q, ldq, nullptr, 4, nullptr, 4, out, ldo, B, N, n_stride_rows, M, m_stride_rows, dh_pad, 1.0f, nullptr, s, kp, vp, n_pad / 4, lnq);
 }
 
 void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale,

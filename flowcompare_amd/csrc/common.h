@@ -188,8 +188,10 @@ void launch_change_map(float* lp10, int N, float* lp00, int N0, float* out, int 
 void launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                       int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, void* limb_ws, hipStream_t s);
 bool attention_fp16_enabled();
+// un-normalised q of the LayerNorm -> q fold: the attention kernel finishes it (rstd from the per-row sums of squares, bias) on load
+struct AttnLnq { const float* sumsq; int slots; size_t pitch; float inv_width; const float* bias; };
 void launch_attention_c16(const float* q, int ldq, const unsigned short* kv_c16, int n_pad, int col0, float* out, int ldo, int B, int N,
-                          int n_stride_rows, int M, int m_stride_rows, int dh_pad, hipStream_t s);
+                          int n_stride_rows, int M, int m_stride_rows, int dh_pad, hipStream_t s, const AttnLnq* lnq = nullptr);
 void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale,
                          void* limb_ws, hipStream_t s);
 void launch_base_density(const float* x, int ldx, int d1, int d1_pad, int d2, float* logprob, float log_const,

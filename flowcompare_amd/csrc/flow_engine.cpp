@@ -543,13 +543,16 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
             e.C = w.q; e.ldc = d.I_pad; e.d2 = d.A_in; e.ldj_part = w.lnss; e.ldj_pitch = (size_t)w.P_pad; e.rows_valid = w.P;
             ASeg a{w.h[cur], ldh};
             launch_gemm(at.lnq, &a, w.P_pad, e, EPI_LNQ, s);
-            launch_lnq_finalize(w.q, d.I_pad, w.lnss, d.A_in / 64, (size_t)w.P_pad, d.A_in, at.q_bias, w.P, s);
-            if (w.kv_limbs)
+            if (w.kv_limbs) {
+                // the attention kernel applies rstd and the bias while it loads its queries
+                const AttnLnq lq{w.lnss, d.A_in / 64, (size_t)w.P_pad, 1.0f / (float)d.A_in, at.q_bias};
                 launch_attention_c16(w.q, d.I_pad, reinterpret_cast<const unsigned short*>(w.kv), w.ldkv, at.kv_col, w.a, d.I_pad, B, N, N, M, M,
-                                     d.I_pad, s);
-            else
+                                     d.I_pad, s, &lq);
+            } else {
+                launch_lnq_finalize(w.q, d.I_pad, w.lnss, d.A_in / 64, (size_t)w.P_pad, d.A_in, at.q_bias, w.P, s);
                 launch_attention(w.q, d.I_pad, w.kv + at.kv_col, w.ldkv, w.kv + at.kv_col + d.I_pad, w.ldkv, w.a, d.I_pad, B, N, N, M, M, d.I_pad,
                                  w.kv16, s);
+            }
             return;
         }
         int o = 0;
