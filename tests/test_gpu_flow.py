@@ -224,3 +224,24 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     finally:
         for k, v in defaults.items():
             lib.fc_debug_set(k, v)
+
+
+def test_c2_layer_widths_with_ragged_sizes_match_the_oracle():
+    """The shipped C2 fast paths (fused spline epilogue with its limb chain, LayerNorm -> q fold, K|V limb images, split-fp16
+    attention) at the real layer widths but ragged sizes: rows not a multiple of any tile (3 x 333 targets), 77 context points
+    (one partial key tile, k-NN with k = 40 of 77)."""
+    cfg = fa.named_config("c2_dgcnn_attn_spline", n_flow_layers=2, sample_size=333)
+    torch.manual_seed(9)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    g = torch.Generator().manual_seed(10)
+    B, N, M = 3, 333, 77
+    e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
+    eps = [torch.randn(B, N, 294, generator=g)]
+    loss, lp, bpd = fa.inner_loop((e0.to(DEV), e1.to(DEV), None), md, cfg, eps=[e.to(DEV) for e in eps])
+    sd_f = {k: v.cpu().double() for k, v in md["flow"].state_dict().items()}
+    sd_e = {k: v.cpu().double() for k, v in md["input_embedder"].state_dict().items()}
+    with torch.no_grad():
+        _, lp_o, bpd_o = O.inner_loop(cfg, sd_f, sd_e, (e0.double(), e1.double(), None), [e.double() for e in eps])
+    d = (lp.cpu().double() - lp_o).abs()
+    print(f"ragged C2: max {d.max():.2e} mean {d.mean():.2e} bpd diff {abs(float(bpd) - float(bpd_o)):.2e}")
+    assert lp.shape == (B, N) and abs(float(bpd) - float(bpd_o)) < BPD_TOL and d.max() < PER_POINT_TOL
