@@ -398,7 +398,6 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
     d.E = c.input_embedding_dim; d.E_pad = round_up(d.E, 32); d.X = c.extra_context_dim;
     if (d.Din > 32) throw Error(FC_ERR_UNSUPPORTED, "input_dim > 32");
     d.Dc = c.cif_latent_dim; d.nz = d.Dc - d.D; d.nz_pad = round_up(std::max(d.nz, 1), 32);
-    if (cif && d.D > 160) throw Error(FC_ERR_UNSUPPORTED, "CIFblock with latent_dim > 160 is not supported yet (single-tile affine_cif epilogue)");
     std::vector<MatD> kv_rows;
 
     // ---- transform 0: AugmentAttentionPreconditioner (models/augmenter.py:7-22) or IdentityTransform

@@ -245,3 +245,50 @@ def test_c2_layer_widths_with_ragged_sizes_match_the_oracle():
     d = (lp.cpu().double() - lp_o).abs()
     print(f"ragged C2: max {d.max():.2e} mean {d.mean():.2e} bpd diff {abs(float(bpd) - float(bpd_o)):.2e}")
     assert lp.shape == (B, N) and abs(float(bpd) - float(bpd_o)) < BPD_TOL and d.max() < PER_POINT_TOL
+
+
+def test_cif_stack_at_real_layer_widths_matches_the_oracle():
+    """CIFblock (augment -> conditional affine -> slice around the attention-conditioned coupling, models/cif_block.py:49-112) at the
+    real layer widths (latent 300, CIF latent 364): the pair-packed epilogues on the eight-wave tile with slot-buffered log-dets,
+    against the fp64 oracle on fresh inputs."""
+    cfg = fa.named_config("c2_dgcnn_attn_spline", flow_type="AffineCoupling", n_flow_layers=2, sample_size=150, cif_latent_dim=364,
+                          net_cif_dist_hidden_dims=[64, 64], affine_cif_hidden=[256, 256, 256])
+    torch.manual_seed(13)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    g = torch.Generator().manual_seed(14)
+    B, N, M = 2, 150, 160
+    e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
+    eps = [torch.randn(*s, generator=g) for s in md["flow"].noise_shapes(B, N)]
+    assert len(eps) == 3                                             # the outer augmenter + one per CIF block
+    loss, lp, bpd = fa.inner_loop((e0.to(DEV), e1.to(DEV), None), md, cfg, eps=[e.to(DEV) for e in eps])
+    sd_f = {k: v.cpu().double() for k, v in md["flow"].state_dict().items()}
+    sd_e = {k: v.cpu().double() for k, v in md["input_embedder"].state_dict().items()}
+    with torch.no_grad():
+        _, lp_o, bpd_o = O.inner_loop(cfg, sd_f, sd_e, (e0.double(), e1.double(), None), [e.double() for e in eps])
+    d = (lp.cpu().double() - lp_o).abs()
+    print(f"CIF real widths: max {d.max():.2e} mean {d.mean():.2e} bpd diff {abs(float(bpd) - float(bpd_o)):.2e}")
+    assert abs(float(bpd) - float(bpd_o)) < BPD_TOL and d.max() < PER_POINT_TOL
+    # the tiles the range guard falls back to (bf16 limbs on the 128x320 tile, two column tiles -> atomics on the log-prob) and the
+    # fp32-input MFMA variant run the same pair epilogues
+    from flowcompare_amd import engine
+    lib = engine.lib()
+    try:
+        for name, v in (("bf16-limb GEMM", 3), ("fp32-input MFMA GEMM", 2)):
+            lib.fc_debug_set(0, v)
+            _, lp_v, _ = fa.inner_loop((e0.to(DEV), e1.to(DEV), None), md, cfg, eps=[e.to(DEV) for e in eps])
+            err = (lp_v.cpu().double() - lp_o).abs().max().item()
+            print(f"CIF real widths, {name}: max {err:.2e}")
+            assert err < PER_POINT_TOL, name
+    finally:
+        lib.fc_debug_set(0, 5)
+    # the inverse pass (Slice.inverse draws z2, then the affine_cif inverse epilogue) at the same widths, against the oracle's
+    h = md["flow"]._engine()
+    emb = md["input_embedder"](e0.to(DEV))
+    z = torch.randn(B, N, 300, generator=g) * 0.5
+    xr = h.inverse(z.to(DEV), emb, None, [e.to(DEV) for e in eps[1:]])
+    with torch.no_grad():
+        ctx_o = O.context_embed(cfg, sd_e, e0.double())
+        x_o = O.flow_inverse(cfg, sd_f, z.double(), ctx_o, None, [e.double() for e in eps[1:]])
+    rt = (xr.cpu().double() - x_o).abs().max().item() / max(1.0, x_o.abs().max().item())
+    print(f"CIF real widths: inverse vs oracle, max relative to |x|max {rt:.2e}")
+    assert rt < 5e-4
