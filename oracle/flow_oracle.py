@@ -10,6 +10,9 @@ flowcompare_amd never does.
 Parity status: PINNED.  tests/test_oracle_golden.py checks every function
 below against golden vectors produced by running the reference itself in the
 build container (tests/golden/gen_golden.py; fixtures tests/golden/*.npz).
+Being eager PyTorch, it is differentiable: tests/test_oracle_grads.py pins its
+autograd gradients (the backward of the path) to gradients
+of the reference's own loss.backward() (tests/golden/gen_golden_grads.py).
 
 It is written functionally over a flat state_dict (name -> tensor) whose key
 names are the reference's checkpoint names, so a reference
@@ -443,10 +446,31 @@ def knn_indices(f, k):
     return pd.topk(k, dim=-1)[1]
 
 
+BN_BATCH_STATS = False      # set by train_mode(): BatchNorm normalises with the batch's own biased statistics (module.train())
+
+
+class train_mode:
+    """Context manager: the embedder's BatchNorms use batch statistics, as after `.train()` (train.py:46-47 builds the models in
+    'train' mode).  The flow itself computes the same function in both modes once ActNorm is initialised (act_norm.py:38-39);
+    torch.utils.checkpoint (cif_block.py:17-19) only changes what is stored.  Running statistics are not updated here."""
+    def __enter__(self):
+        global BN_BATCH_STATS
+        self.prev, BN_BATCH_STATS = BN_BATCH_STATS, True
+
+    def __exit__(self, *a):
+        global BN_BATCH_STATS
+        BN_BATCH_STATS = self.prev
+
+
 def _bn(sd, prefix, y):
-    """eval-mode BatchNorm (running stats, eps 1e-5) on channels-last y."""
-    inv = torch.rsqrt(sd[f"{prefix}.running_var"] + 1e-5)
-    return (y - sd[f"{prefix}.running_mean"]) * inv * sd[f"{prefix}.weight"] + sd[f"{prefix}.bias"]
+    """BatchNorm (eps 1e-5) on channels-last y: running statistics in eval mode, the batch's biased statistics over every leading
+    axis in train mode (torch.nn.BatchNorm1d/2d semantics)."""
+    if BN_BATCH_STATS:
+        dims = tuple(range(y.dim() - 1))
+        mean, var = y.mean(dims), y.var(dims, unbiased=False)
+    else:
+        mean, var = sd[f"{prefix}.running_mean"], sd[f"{prefix}.running_var"]
+    return (y - mean) * torch.rsqrt(var + 1e-5) * sd[f"{prefix}.weight"] + sd[f"{prefix}.bias"]
 
 
 def edge_conv(sd, level, f, k):
