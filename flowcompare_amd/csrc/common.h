@@ -151,6 +151,13 @@ struct Fp16Guard {
     bool overflowed();            // closes the scope: waits for the stream and reads the flag
     int* flag; hipStream_t stream; bool open;
 };
+// Training primitives (train.hip): the CALLER owns the overflow flag for a whole optimisation step (forward and backward run on
+// different host threads under torch.autograd), so the scope only lends it to launch_gemm for one call -- no reset, no wait.
+struct Fp16FlagScope {
+    explicit Fp16FlagScope(int* dev_flag);
+    ~Fp16FlagScope();
+    int* prev;
+};
 bool gemm_fp16_enabled();
 bool gemm_limb_chain_ok();
 bool gemm_lnq_ok();             // the LayerNorm -> q fold (EPI_LNQ) can run: guard scope open, default tile

@@ -585,6 +585,8 @@ Fp16Guard::Fp16Guard(int* dev_flag, hipStream_t s) : flag(dev_flag), stream(s), 
     t_fp16_flag = flag;
 }
 Fp16Guard::~Fp16Guard() { t_fp16_flag = nullptr; }
+Fp16FlagScope::Fp16FlagScope(int* dev_flag) : prev(t_fp16_flag) { t_fp16_flag = dev_flag; }
+Fp16FlagScope::~Fp16FlagScope() { t_fp16_flag = prev; }
 bool Fp16Guard::overflowed() {
     t_fp16_flag = nullptr;
     open = false;

@@ -1,0 +1,431 @@
+// Training primitives: the backward of the hot path, first slice = the residual GELU MLP (models/nets.py:19-30),
+// which is ~61 % of the reference's forward time and two thirds of its backward FLOPs.
+//
+// The training path keeps parameters as ordinary dense fp32 tensors (they change every optimiser step), so nothing is folded at
+// create time as in the inference engine.  Per step and per Linear the caller
+//   * packs  W [N, K] -> the operand images of the split-fp16 GEMM loop (gemm.hip), for W and for W^T           (train_pack_kernel)
+//   * forward   u = x W^T + b (+ residual),  y = act(u)             launch_gemm on the packed W   + act kernel
+//   * backward  du = dy . act'(u)                                    act_bwd_kernel
+//               dx = du W                                            launch_gemm on the packed W^T (same split-fp16 tile as the forward)
+//               dW = du^T x ,  db = column sums of du                wgrad_kernel (fp32-input MFMA, rows split over workgroups,
+//                                                                    partial tiles reduced in a fixed order: bit-reproducible)
+// Activations are "panels": row-major fp32 [rows_pad, width_pad], rows padded to ROW_PAD, widths to 32 with ZERO pad columns.
+// An input may be up to three panels side by side (the coupling MLP reads cat(x1, attention output), models/affine_coupling.py:33),
+// exactly like launch_gemm's A segments.
+//
+// Range: the split-fp16 loop needs |operand| < 65504.  The caller owns ONE device flag per optimisation step (forward and backward
+// run on different host threads under torch.autograd, so no thread-local scope can span them); every primitive ORs into it and the
+// caller repeats the step with flag == NULL (fp32-input MFMA loop, any range) if it came back set.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "activations.h"
+#include "common.h"
+
+namespace fc {
+
+struct TrainLinearLayout {
+    int N, N_pad, n_alloc;                 // output features: true, padded to 32, rows of the packed W (column-tile grid)
+    int nseg, seg[3], seg_pad[3];          // input panels: true and padded widths
+    int K, K_pad, k_alloc;                 // sums; rows of the packed W^T
+    size_t off_W, off_W2, off_bias, off_WT, off_WT2, bytes;
+};
+
+static TrainLinearLayout train_layout(int N, const int32_t* seg, int nseg) {
+    if (N < 1 || nseg < 1 || nseg > 3 || !seg) throw Error(FC_ERR_INVALID, "training Linear: need N >= 1 and 1..3 input segments");
+    TrainLinearLayout L{};
+    L.N = N; L.N_pad = round_up(N, 32); L.n_alloc = gemm_n_alloc(L.N_pad);
+    L.nseg = nseg;
+    for (int i = 0; i < nseg; ++i) {
+        if (seg[i] < 1) throw Error(FC_ERR_INVALID, "training Linear: empty input segment");
+        L.seg[i] = seg[i]; L.seg_pad[i] = round_up(seg[i], 32);
+        L.K += seg[i]; L.K_pad += L.seg_pad[i];
+    }
+    L.k_alloc = gemm_n_alloc(L.K_pad);
+    size_t o = 0;
+    auto take = [&](size_t b) { const size_t r = o; o = round_up_sz(o + b, 256); return r; };
+    L.off_W = take((size_t)L.n_alloc * L.K_pad * 4);
+    L.off_W2 = take((size_t)L.n_alloc * L.K_pad * 4);          // [n_alloc][K_pad/16][hi 16 | lo' 16] halfs
+    L.off_bias = take((size_t)L.n_alloc * 4);
+    L.off_WT = take((size_t)L.k_alloc * L.N_pad * 4);
+    L.off_WT2 = take((size_t)L.k_alloc * L.N_pad * 4);
+    L.bytes = o;
+    return L;
+}
+
+__device__ __forceinline__ int padded_to_true_k(const TrainLinearLayout& d, int kp) {
+    int pad0 = 0, true0 = 0;
+    for (int i = 0; i < d.nseg; ++i) {
+        if (kp < pad0 + d.seg_pad[i]) {
+            const int l = kp - pad0;
+            return l < d.seg[i] ? true0 + l : -1;
+        }
+        pad0 += d.seg_pad[i]; true0 += d.seg[i];
+    }
+    return -1;
+}
+
+__device__ __forceinline__ void store_limbs(unsigned short* image, size_t row, int kt16, int k, float x, int* ovf) {
+    if (x != 0.f && !(fabsf(x) < 65504.0f) && ovf) atomicOr(ovf, 1);
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+    unsigned short* dst = image + (row * kt16 + (k >> 4)) * 32 + (k & 15);
+    dst[0] = __builtin_bit_cast(unsigned short, h);
+    dst[16] = __builtin_bit_cast(unsigned short, l);
+}
+
+// W [N, K] dense -> zero-padded fp32 + fp16 limb images of W ([n_alloc][K_pad]) and of W^T ([k_alloc][N_pad]), padded bias
+__global__ void train_pack_kernel(const float* __restrict__ W, const float* __restrict__ bias, TrainLinearLayout d, char* pack, int* ovf) {
+    float* Wp = (float*)(pack + d.off_W);
+    unsigned short* W2 = (unsigned short*)(pack + d.off_W2);
+    float* bp = (float*)(pack + d.off_bias);
+    float* WT = (float*)(pack + d.off_WT);
+    unsigned short* WT2 = (unsigned short*)(pack + d.off_WT2);
+    const size_t nA = (size_t)d.n_alloc * d.K_pad, nB = (size_t)d.k_alloc * d.N_pad;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nA; i += stride) {
+        const int n = (int)(i / d.K_pad), kp = (int)(i % d.K_pad);
+        const int k = n < d.N ? padded_to_true_k(d, kp) : -1;
+        const float x = k >= 0 ? W[(size_t)n * d.K + k] : 0.f;
+        Wp[i] = x;
+        store_limbs(W2, n, d.K_pad >> 4, kp, x, ovf);
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nB; i += stride) {
+        const int kp = (int)(i / d.N_pad), n = (int)(i % d.N_pad);
+        const int k = (kp < d.K_pad && n < d.N) ? padded_to_true_k(d, kp) : -1;
+        const float x = k >= 0 ? W[(size_t)n * d.K + k] : 0.f;
+        WT[i] = x;
+        store_limbs(WT2, kp, d.N_pad >> 4, n, x, ovf);
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)d.n_alloc; i += stride)
+        bp[i] = (bias && (int)i < d.N) ? bias[i] : 0.f;
+}
+
+// ---------------------------------------------------------------- activations (models/nets.py:21-29; GELU = exact erf form)
+__device__ __forceinline__ float act_grad(float u, int act) {
+    switch (act) {
+        case FC_ACT_GELU: {
+            // d/du [u Phi(u)] = Phi(u) + u phi(u)
+            const float cdf = 0.5f * erfcf(-u * 0.70710678118654752440f);
+            return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+        }
+        case FC_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+        case FC_ACT_ELU: return u > 0.f ? 1.f : expf(u);
+        case FC_ACT_LRELU02: return u > 0.f ? 1.f : 0.2f;
+        default: return 1.f;
+    }
+}
+
+__global__ void act_fwd_kernel(const float4* __restrict__ u, float4* __restrict__ y, size_t n4, int act) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = u[i];
+        v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+        y[i] = v;
+    }
+}
+
+// du = dy * act'(u) on a dense [rows_pad, ld] panel; rows >= rows_valid come out as zeros (they must not reach weight gradients)
+__global__ void act_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ u, float4* __restrict__ du, size_t n4, size_t valid4,
+                               int act) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < valid4) {
+            const float4 a = dy[i], b = u[i];
+            g.x = a.x * act_grad(b.x, act); g.y = a.y * act_grad(b.y, act); g.z = a.z * act_grad(b.z, act); g.w = a.w * act_grad(b.w, act);
+        }
+        du[i] = g;
+    }
+}
+
+// ---------------------------------------------------------------- weight gradient  dW[n][k] = sum_p du[p][n] x[p][k]
+// Both operands are row-major with the contraction index p as the slow one, which is exactly the operand order of
+// v_mfma_f32_32x32x2_f32 (lane l supplies A[m = l % 32][k = l / 32] and B[k = l / 32][n = l % 32]): 32 consecutive floats of one row
+// per half-wave, no transposition anywhere.  Workgroup = 4 waves, tile 128 (n) x 128 (k), each wave 64 x 64; grid.y splits the rows.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WG_PS = 16;                  // rows per staged slab
+constexpr int WG_LD = 128 + 4;             // LDS pitch in floats
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ du, int ldu, int du_cols, const float* __restrict__ x, int ldx,
+                                                    int x_cols, int rows_valid, int chunk_rows, int tiles_k, float* __restrict__ part,
+                                                    int part_rows, int part_ld) {
+    __shared__ float sA[WG_PS * WG_LD];
+    __shared__ float sB[WG_PS * WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int p_begin = blockIdx.y * chunk_rows, p_end = min(rows_valid, p_begin + chunk_rows);
+    // staging: thread t moves 2 float4 per operand per slab: rows (t / 32) and (t / 32) + 8, columns 4 (t % 32) ...
+    const int lr = tid >> 5, lc = (tid & 31) * 4;
+    const bool a_ok = n0 + lc < du_cols, b_ok = k0 + lc < x_cols;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[2], rb[2];
+    auto gload = [&](int p0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int p = p0 + lr + 8 * h;
+            const bool ok = p < p_end;
+            ra[h] = (ok && a_ok) ? *reinterpret_cast<const float4*>(du + (size_t)p * ldu + n0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[h] = (ok && b_ok) ? *reinterpret_cast<const float4*>(x + (size_t)p * ldx + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (p_begin < p_end) gload(p_begin);
+    for (int p0 = p_begin; p0 < p_end; p0 += WG_PS) {
+        __syncthreads();                                  // the previous slab's reads are done
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(&sA[(lr + 8 * h) * WG_LD + lc]) = ra[h];
+            *reinterpret_cast<float4*>(&sB[(lr + 8 * h) * WG_LD + lc]) = rb[h];
+        }
+        __syncthreads();
+        if (p0 + WG_PS < p_end) gload(p0 + WG_PS);
+#pragma unroll
+        for (int kk = 0; kk < WG_PS / 2; ++kk) {
+            const int row = 2 * kk + (lane >> 5);
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = sA[row * WG_LD + wn * 64 + i * 32 + (lane & 31)];
+                b[i] = sB[row * WG_LD + wk * 64 + i * 32 + (lane & 31)];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* out = part + (size_t)blockIdx.y * part_rows * part_ld;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+                out[(size_t)n * part_ld + k] = acc[i][j][r];
+            }
+}
+
+// dW[n][k_off + k] (=|+=) sum_s part[s][n][k]   for n < N, k < k_true: fixed summation order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int part_rows, int part_ld, float* __restrict__ dW, int N, int K,
+                                    int k_off, int k_true, int accumulate) {
+    const size_t total = (size_t)N * k_true;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / k_true), k = (int)(i % k_true);
+        float s = 0.f;
+        for (int c = 0; c < S; ++c) s += part[((size_t)c * part_rows + n) * part_ld + k];
+        float* dst = dW + (size_t)n * K + k_off + k;
+        *dst = accumulate ? *dst + s : s;
+    }
+}
+
+// column sums over rows [0, rows_valid): part[s][col] then a fixed-order reduce (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int lda, int cols, int rows_valid, int chunk_rows,
+                                                     float* __restrict__ part, int part_ld) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int p_begin = blockIdx.y * chunk_rows, p_end = min(rows_valid, p_begin + chunk_rows);
+    float s = 0.f;
+    if (c < cols)
+        for (int p = p_begin + q; p < p_end; p += 4) s += a[(size_t)p * lda + c];
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < cols) part[(size_t)blockIdx.y * part_ld + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void colsum_reduce_kernel(const float* __restrict__ part, int S, int part_ld, float* __restrict__ out, int n, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += part[(size_t)i * part_ld + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---------------------------------------------------------------- host side
+static int grid_for(size_t n, int block) { return (int)std::min<size_t>((n + block - 1) / block, 256 * 16); }
+
+struct WgradPlan { int S, chunk, n128, k128max; size_t part_floats, colsum_floats, bytes; };
+static WgradPlan wgrad_plan(const TrainLinearLayout& L, int rows) {
+    WgradPlan w{};
+    w.n128 = round_up(L.N_pad, 128);
+    int tiles_max = 1;
+    for (int i = 0; i < L.nseg; ++i) {
+        w.k128max = std::max(w.k128max, round_up(L.seg_pad[i], 128));
+        tiles_max = std::max(tiles_max, (w.n128 / 128) * (round_up(L.seg_pad[i], 128) / 128));
+    }
+    // enough workgroups for 256 CUs x 2, slabs of at least 512 rows
+    w.S = std::max(1, std::min(std::max(1, 1024 / tiles_max), std::max(1, rows / 512)));
+    w.chunk = round_up((rows + w.S - 1) / w.S, WG_PS);
+    w.part_floats = (size_t)w.S * w.n128 * w.k128max;
+    w.colsum_floats = (size_t)w.S * L.N_pad;
+    w.bytes = round_up_sz(w.part_floats * 4, 256) + round_up_sz(w.colsum_floats * 4, 256);
+    return w;
+}
+
+static PackedLinear packed_forward(const TrainLinearLayout& L, const void* pack, bool f16) {
+    const char* b = (const char*)pack;
+    PackedLinear P;
+    P.W = (float*)(b + L.off_W);
+    P.W2 = f16 ? (unsigned short*)(b + L.off_W2) : nullptr;
+    P.bias = (float*)(b + L.off_bias);
+    P.N_pad = L.N_pad; P.K_pad = L.K_pad; P.nseg = L.nseg;
+    for (int i = 0; i < L.nseg; ++i) P.seg_k[i] = L.seg_pad[i];
+    P.n_true = L.N; P.k_true = L.K; P.n_alloc = L.n_alloc;
+    return P;
+}
+static PackedLinear packed_transposed(const TrainLinearLayout& L, const void* pack, bool f16) {
+    const char* b = (const char*)pack;
+    PackedLinear P;
+    P.W = (float*)(b + L.off_WT);
+    P.W2 = f16 ? (unsigned short*)(b + L.off_WT2) : nullptr;
+    P.bias = nullptr;
+    P.N_pad = L.K_pad; P.K_pad = L.N_pad; P.nseg = 1; P.seg_k[0] = L.N_pad;
+    P.n_true = L.K; P.k_true = L.N; P.n_alloc = L.k_alloc;
+    return P;
+}
+
+static void check_panel(const void* p, int ld, int width_pad, const char* what) {
+    if (!p || ld < width_pad || ld % 4 != 0 || ((uintptr_t)p & 15)) throw Error(FC_ERR_INVALID, std::string("training Linear: bad panel for ") + what);
+}
+
+}  // namespace fc
+
+#define FC_API_BEGIN try {
+#define FC_API_END                                                                            \
+    }                                                                                         \
+    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }               \
+    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; }  \
+    return FC_OK;
+
+using namespace fc;
+
+extern "C" {
+
+size_t fc_train_linear_pack_bytes(int32_t N, const int32_t* seg_widths, int32_t nseg) {
+    try { return train_layout(N, seg_widths, nseg).bytes; } catch (const std::exception& e) { set_last_error(e.what()); return 0; }
+}
+
+int fc_train_linear_pack_f32(const float* W, const float* bias, int32_t N, const int32_t* seg_widths, int32_t nseg, void* pack, size_t pack_bytes,
+                             int32_t* ovf, void* stream) {
+    FC_API_BEGIN
+    const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
+    if (!W || !pack || pack_bytes < L.bytes || ((uintptr_t)pack & 255)) throw Error(FC_ERR_INVALID, "fc_train_linear_pack_f32: bad argument (pack must be 256-byte aligned, fc_train_linear_pack_bytes long)");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = std::max((size_t)L.n_alloc * L.K_pad, (size_t)L.k_alloc * L.N_pad);
+    ProfScope ps("fc::train_pack_kernel", 0.0, (double)n * 16.0, s);
+    hipLaunchKernelGGL(train_pack_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, W, bias, L, (char*)pack, (int*)ovf);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_linear_fwd_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* const* x, const int32_t* ldx,
+                            int32_t rows_pad, const float* residual, int32_t ldr, float* u, int32_t ldu, int32_t* ovf, void* stream) {
+    FC_API_BEGIN
+    const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
+    if (!pack || !x || !ldx || rows_pad < 1 || rows_pad % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "fc_train_linear_fwd_f32: bad argument (rows_pad must be a multiple of 256)");
+    ASeg a[3] = {};
+    for (int i = 0; i < L.nseg; ++i) { check_panel(x[i], ldx[i], L.seg_pad[i], "x"); a[i] = ASeg{x[i], ldx[i]}; }
+    check_panel(u, ldu, L.N_pad, "u");
+    if (residual) check_panel(residual, ldr, L.N_pad, "residual");
+    const PackedLinear P = packed_forward(L, pack, ovf != nullptr);
+    GemmEpi e{};
+    e.C = u; e.ldc = ldu; e.residual = residual; e.ldr = ldr; e.rows_valid = rows_pad;
+    Fp16FlagScope scope((int*)ovf);
+    launch_gemm(P, a, rows_pad, e, EPI_LINEAR, (hipStream_t)stream);
+    FC_API_END
+}
+
+int fc_train_linear_dgrad_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu, int32_t rows_pad,
+                              float* dx, int32_t lddx, int32_t* ovf, void* stream) {
+    FC_API_BEGIN
+    const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
+    if (!pack || rows_pad < 1 || rows_pad % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "fc_train_linear_dgrad_f32: bad argument (rows_pad must be a multiple of 256)");
+    check_panel(du, ldu, L.N_pad, "du");
+    check_panel(dx, lddx, L.K_pad, "dx");
+    const PackedLinear P = packed_transposed(L, pack, ovf != nullptr);
+    ASeg a{du, ldu};
+    GemmEpi e{};
+    e.C = dx; e.ldc = lddx; e.rows_valid = rows_pad;
+    Fp16FlagScope scope((int*)ovf);
+    launch_gemm(P, &a, rows_pad, e, EPI_LINEAR, (hipStream_t)stream);
+    FC_API_END
+}
+
+size_t fc_train_linear_wgrad_ws_bytes(int32_t N, const int32_t* seg_widths, int32_t nseg, int32_t rows) {
+    try { return wgrad_plan(train_layout(N, seg_widths, nseg), rows).bytes; } catch (const std::exception& e) { set_last_error(e.what()); return 0; }
+}
+
+int fc_train_linear_wgrad_f32(int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu, const float* const* x,
+                              const int32_t* ldx, int32_t rows, float* dW, float* db, int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+    FC_API_BEGIN
+    const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
+    if (!x || !ldx || rows < 1 || (!dW && !db)) throw Error(FC_ERR_INVALID, "fc_train_linear_wgrad_f32: bad argument");
+    check_panel(du, ldu, L.N_pad, "du");
+    const WgradPlan w = wgrad_plan(L, rows);
+    if (!ws || ws_bytes < w.bytes || ((uintptr_t)ws & 255)) throw Error(FC_ERR_WORKSPACE, "fc_train_linear_wgrad_f32: workspace too small (fc_train_linear_wgrad_ws_bytes) or not 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* part = (float*)ws;
+    float* cpart = (float*)((char*)ws + round_up_sz(w.part_floats * 4, 256));
+    if (dW) {
+        int k_off = 0;
+        for (int i = 0; i < L.nseg; ++i) {
+            check_panel(x[i], ldx[i], L.seg_pad[i], "x");
+            const int k128 = round_up(L.seg_pad[i], 128), tiles_k = k128 / 128, tiles_n = w.n128 / 128;
+            {
+                ProfScope ps("fc::wgrad_kernel", 2.0 * rows * (double)L.N * L.seg[i], 0.0, s);
+                hipLaunchKernelGGL(wgrad_kernel, dim3(tiles_n * tiles_k, w.S), dim3(256), 0, s, du, ldu, L.N_pad, x[i], ldx[i], L.seg_pad[i], rows,
+                                   w.chunk, tiles_k, part, w.n128, k128);
+                FC_HIP(hipGetLastError());
+            }
+            const size_t total = (size_t)L.N * L.seg[i];
+            ProfScope ps("fc::wgrad_reduce_kernel", 0.0, (double)total * 4.0 * (w.S + 1), s);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, part, w.S, w.n128, k128, dW, L.N, L.K, k_off,
+                               L.seg[i], accumulate);
+            FC_HIP(hipGetLastError());
+            k_off += L.seg[i];
+        }
+    }
+    if (db) {
+        ProfScope ps("fc::colsum_kernel", 0.0, (double)rows * L.N * 4.0, s);
+        hipLaunchKernelGGL(colsum_kernel, dim3((L.N + 63) / 64, w.S), dim3(256), 0, s, du, ldu, L.N, rows, w.chunk, cpart, L.N_pad);
+        FC_HIP(hipGetLastError());
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((L.N + 255) / 256), dim3(256), 0, s, cpart, w.S, L.N_pad, db, L.N, accumulate);
+        FC_HIP(hipGetLastError());
+    }
+    FC_API_END
+}
+
+int fc_train_act_fwd_f32(const float* u, float* y, int32_t rows_pad, int32_t ld, int32_t act, void* stream) {
+    FC_API_BEGIN
+    if (!u || !y || rows_pad < 1 || ld < 4 || ld % 4 != 0 || (((uintptr_t)u | (uintptr_t)y) & 15)) throw Error(FC_ERR_INVALID, "fc_train_act_fwd_f32: bad argument");
+    const size_t n4 = (size_t)rows_pad * ld / 4;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::act_fwd_kernel", 0.0, (double)n4 * 32.0, s);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, (const float4*)u, (float4*)y, n4, act);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_act_bwd_f32(const float* dy, const float* u, float* du, int32_t rows_pad, int32_t rows, int32_t ld, int32_t act, void* stream) {
+    FC_API_BEGIN
+    if (!dy || !u || !du || rows_pad < 1 || rows < 0 || rows > rows_pad || ld < 4 || ld % 4 != 0 || (((uintptr_t)u | (uintptr_t)dy | (uintptr_t)du) & 15))
+        throw Error(FC_ERR_INVALID, "fc_train_act_bwd_f32: bad argument");
+    const size_t n4 = (size_t)rows_pad * ld / 4, v4 = (size_t)rows * ld / 4;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::act_bwd_kernel", 0.0, (double)n4 * 48.0, s);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, (const float4*)dy, (const float4*)u, (float4*)du, n4, v4, act);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+}  // extern "C"

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FCFLOW_LIB", os.path.join(_HERE, "libfcflow.so"))   # FCFLOW_LIB: A/B another build in profiles/kernel_bench.py
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 FLOW_TYPES = {"AffineCoupling": 0, "RationalQuadraticSplineCoupling": 1, "ExponentialCoupling": 2}
 SCALE_FNS = {"exp": 0, "sigmoid": 1}
@@ -28,6 +28,8 @@ EXPORTS = [
     "fc_profile_enable", "fc_profile_reset", "fc_profile_filter", "fc_profile_report",
     "fc_op_linear_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
     "fc_stage_fps_f32", "fc_stage_co_unit_sphere_f32", "fc_clamp_infs_f32", "fc_change_map_f32",
+    "fc_train_linear_pack_bytes", "fc_train_linear_pack_f32", "fc_train_linear_fwd_f32", "fc_train_linear_dgrad_f32",
+    "fc_train_linear_wgrad_ws_bytes", "fc_train_linear_wgrad_f32", "fc_train_act_fwd_f32", "fc_train_act_bwd_f32",
 ]
 
 
@@ -63,6 +65,8 @@ def lib():
         L.fc_flow_destroy.restype = None
         L.fc_dgcnn_destroy.restype = None
         L.fc_paconv_destroy.restype = None
+        L.fc_train_linear_pack_bytes.restype = ctypes.c_size_t
+        L.fc_train_linear_wgrad_ws_bytes.restype = ctypes.c_size_t
         if L.fc_abi_version() != ABI_VERSION:
             raise RuntimeError("libfcflow.so ABI version mismatch: rebuild with `python -m flowcompare_amd.build --force`")
         _lib = L

@@ -1,0 +1,202 @@
+"""Training path, first slice: the residual MLP of models/nets.py:19-30 as torch.autograd Functions whose
+forward AND backward are HIP kernels behind the C ABI (include/fcflow.h, fc_train_*; kernels in csrc/train.hip + the GEMM of the
+inference path).  torch is plumbing: it owns the tensors, the stream and the autograd graph between the primitives; there is no
+PyTorch arithmetic on activations here and no CPU fallback.
+
+Activations travel as PANELS: contiguous fp32 [rows_pad, width_pad], rows padded to 256 and widths to 32 with zero pad columns
+(`to_panel` / `from_panel`).  A Linear may read up to three panels side by side, so cat(x1, context) is never materialised.
+
+Range guard: `step_guard()` hands every primitive one device flag for the whole optimisation step (forward and backward run on
+different host threads under autograd); `guard.overflowed()` after backward tells the caller to repeat the step with
+`step_guard(fp16=False)` (fp32-input MFMA loop, any range).  Without a guard the fp32-input loop runs.
+"""
+import ctypes
+import threading
+
+import torch
+
+from . import engine
+
+ROW_PAD = 256
+ACT_IDS = {None: 0, "none": 0, "GELU": 1, "RELU": 2, "ELU": 3}
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def to_panel(x2d):
+    """[rows, C] -> zero-padded panel [round_up(rows, 256), round_up(C, 32)] (differentiable: plain torch padding)."""
+    rows, c = x2d.shape
+    return torch.nn.functional.pad(x2d.to(torch.float32), (0, _round_up(c, 32) - c, 0, _round_up(rows, ROW_PAD) - rows)).contiguous()
+
+
+def from_panel(p, rows, c):
+    return p[:rows, :c]
+
+
+# ---------------------------------------------------------------- per-step state shared by forward and backward threads
+class _Step:
+    flag = None          # int32[1] device tensor or None (fp32-input loop)
+    ws = {}              # device -> uint8 scratch tensor for the weight-gradient partial tiles
+    lock = threading.Lock()
+
+
+class step_guard:
+    """with step_guard() as g: loss = ...; loss.backward()  ;  g.overflowed() -> repeat with step_guard(fp16=False)."""
+
+    def __init__(self, fp16=True, device=None):
+        self.fp16 = fp16
+        self.device = device
+
+    def __enter__(self):
+        self.prev = _Step.flag
+        _Step.flag = torch.zeros(1, dtype=torch.int32, device=self.device or "cuda") if self.fp16 else None
+        self.mine = _Step.flag
+        return self
+
+    def __exit__(self, *a):
+        _Step.flag = self.prev
+
+    def overflowed(self):
+        return self.mine is not None and bool(self.mine.item())
+
+
+def _flag_ptr():
+    return engine._ptr(_Step.flag)
+
+
+def _ws(nbytes, device):
+    with _Step.lock:
+        t = _Step.ws.get(device)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            _Step.ws[device] = t
+        return t
+
+
+def _segs(widths):
+    return (ctypes.c_int32 * len(widths))(*widths)
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _check_panel(t, width):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous() and t.shape[0] % ROW_PAD == 0
+            and t.shape[1] >= _round_up(width, 32)):
+        raise RuntimeError("flowcompare_amd.train_ops: expected a contiguous fp32 HIP panel [rows_pad % 256 == 0, width padded to 32]")
+
+
+class LinearActFn(torch.autograd.Function):
+    """y = act(cat(x...) W^T + b (+ residual)) on panels; forward and backward are HIP kernels (csrc/train.hip)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, residual, act, rows, widths, *xs):
+        L = engine.lib()
+        N, K = weight.shape
+        if sum(widths) != K or len(xs) != len(widths):
+            raise RuntimeError(f"LinearActFn: segment widths {widths} do not add up to in_features {K}")
+        for x, w in zip(xs, widths):
+            _check_panel(x, w)
+        rows_pad = xs[0].shape[0]
+        dev = weight.device
+        w32 = weight.detach().to(torch.float32).contiguous()
+        b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
+        segs = _segs(widths)
+        N_pad = _round_up(N, 32)
+        with torch.cuda.device(dev):
+            nb = L.fc_train_linear_pack_bytes(N, segs, len(widths))
+            pack = torch.empty(nb, dtype=torch.uint8, device=dev)
+            s = engine._stream()
+            engine._check(L.fc_train_linear_pack_f32(engine._ptr(w32), engine._ptr(b32), N, segs, len(widths), engine._ptr(pack),
+                                                     ctypes.c_size_t(nb), _flag_ptr(), s))
+            u = torch.empty(rows_pad, N_pad, dtype=torch.float32, device=dev)
+            ldx = _segs([x.shape[1] for x in xs])
+            if residual is not None:
+                _check_panel(residual, N)
+            engine._check(L.fc_train_linear_fwd_f32(engine._ptr(pack), N, segs, len(widths), _ptr_array(xs), ldx, rows_pad,
+                                                    engine._ptr(residual), 0 if residual is None else residual.shape[1],
+                                                    engine._ptr(u), N_pad, _flag_ptr(), s))
+            if act:
+                y = torch.empty_like(u)
+                engine._check(L.fc_train_act_fwd_f32(engine._ptr(u), engine._ptr(y), rows_pad, N_pad, act, s))
+            else:
+                y = u
+        ctx.save_for_backward(pack, u if act else None, *xs)
+        ctx.meta = (N, K, tuple(widths), act, rows, bias is not None, residual is not None, weight.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = engine.lib()
+        pack, u, *xs = ctx.saved_tensors
+        N, K, widths, act, rows, has_bias, has_res, wdtype = ctx.meta
+        dev = dy.device
+        rows_pad, N_pad = xs[0].shape[0], _round_up(N, 32)
+        dy = dy.contiguous()
+        segs = _segs(widths)
+        need = ctx.needs_input_grad
+        with torch.cuda.device(dev):
+            s = engine._stream()
+            if act:
+                du = torch.empty_like(dy)
+                engine._check(L.fc_train_act_bwd_f32(engine._ptr(dy), engine._ptr(u), engine._ptr(du), rows_pad, rows, N_pad, act, s))
+            else:
+                du = dy
+            dW = db = None
+            if need[0] or (has_bias and need[1]):
+                nb = L.fc_train_linear_wgrad_ws_bytes(N, segs, len(widths), rows)
+                ws = _ws(nb, dev)
+                dW = torch.empty(N, K, dtype=torch.float32, device=dev) if need[0] else None
+                db = torch.empty(N, dtype=torch.float32, device=dev) if (has_bias and need[1]) else None
+                ldx = _segs([x.shape[1] for x in xs])
+                engine._check(L.fc_train_linear_wgrad_f32(N, segs, len(widths), engine._ptr(du), N_pad, _ptr_array(xs), ldx, rows,
+                                                          engine._ptr(dW), engine._ptr(db), 0, engine._ptr(ws), ctypes.c_size_t(nb), s))
+            dxs = [None] * len(xs)
+            if any(need[6:]):
+                K_pad = sum(_round_up(w, 32) for w in widths)
+                dx = torch.empty(rows_pad, K_pad, dtype=torch.float32, device=dev)
+                engine._check(L.fc_train_linear_dgrad_f32(engine._ptr(pack), N, segs, len(widths), engine._ptr(du), N_pad, rows_pad,
+                                                          engine._ptr(dx), K_pad, _flag_ptr(), s))
+                off = 0
+                for i, (x, w) in enumerate(zip(xs, widths)):
+                    wp = _round_up(w, 32)
+                    if need[6 + i]:
+                        g = dx[:, off:off + wp]
+                        if x.shape[1] != wp:                      # a wider panel than the segment reads: its other columns get no gradient
+                            g = torch.nn.functional.pad(g, (0, x.shape[1] - wp))
+                        dxs[i] = g
+                    off += wp
+        if dW is not None:
+            dW = dW.to(wdtype)
+        return (dW, db, du if (has_res and need[2]) else None, None, None, None, *dxs)
+
+
+def linear_act(xs, widths, weight, bias, rows, act=None, residual=None):
+    """act(cat(xs) W^T + b + residual) on panels; `widths` = true widths of the input panels, `rows` = valid rows."""
+    return LinearActFn.apply(weight, bias, residual, ACT_IDS[act] if not isinstance(act, int) else act, rows, tuple(widths), *xs)
+
+
+def mlp_panels(mlp, xs, widths, rows, act):
+    """models/nets.py:19-30 on panels: act(in) ; even hidden layer: r = x, x = act(W x) ; odd: x = act(r + W x) ; out (no activation)."""
+    x = linear_act(xs, widths, mlp.in_layer.weight, mlp.in_layer.bias, rows, act)
+    keep = None
+    for i, layer in enumerate(mlp.layers):
+        w = layer.in_features
+        if i % 2 == 0:
+            keep = x
+            x = linear_act([x], [w], layer.weight, layer.bias, rows, act)
+        else:
+            x = linear_act([x], [w], layer.weight, layer.bias, rows, act, residual=keep)
+    return linear_act([x], [mlp.out_layer.in_features], mlp.out_layer.weight, mlp.out_layer.bias, rows, None)
+
+
+def mlp_forward(mlp, x, act="GELU"):
+    """MLP.forward for an ordinary [..., in_dim] HIP tensor, differentiable w.r.t. x and every parameter of `mlp`."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    rows = x2.shape[0]
+    y = mlp_panels(mlp, [to_panel(x2)], [x2.shape[1]], rows, act)
+    return from_panel(y, rows, mlp.out_layer.out_features).reshape(*lead, -1)

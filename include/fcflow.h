@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 2
+#define FC_ABI_VERSION 3
 
 enum fc_status {
     FC_OK = 0,
@@ -193,6 +193,34 @@ int fc_op_knn_f32(const float* f, int32_t* idx, int32_t B, int32_t M, int32_t C,
  * x [n], params [n, 3K+1] laid out [K widths | K heights | K+1 derivatives] -> y [n], logabsdet [n]. */
 int fc_op_rqspline_f32(const float* x, const float* params, float* y, float* logabsdet,
                        int64_t n, int32_t K, int32_t inverse, void* stream);
+
+/* ---- training primitives: backward of the hot path (first slice = the residual MLP, models/nets.py:19-30) ----
+ * Replaces what torch.autograd does for torch.nn.Linear + activation inside MLP.forward when train.py:112 calls loss.backward().
+ * Parameters stay dense fp32 [N, K] tensors owned by the caller (they change every optimiser step).  Activations are PANELS:
+ * row-major fp32 [rows_pad, width_pad], rows_pad a multiple of 256, widths padded to 32 with ZERO pad columns, 16-byte aligned.
+ * A Linear's input may be 1..3 panels side by side (seg_widths = their true widths, sum = K), e.g. cat(x1, context).
+ * ovf: one device int32 the caller zeroes per optimisation step; non-NULL selects the split-fp16 MFMA loop and the primitives OR 1
+ * into it when an operand leaves the fp16 range (results then invalid: repeat the step with ovf == NULL, the fp32-input MFMA loop). */
+size_t fc_train_linear_pack_bytes(int32_t N, const int32_t* seg_widths, int32_t nseg);
+/* W [N,K], bias [N] | NULL  ->  pack (256-byte aligned, fc_train_linear_pack_bytes long): operand images of W and W^T. */
+int fc_train_linear_pack_f32(const float* W, const float* bias, int32_t N, const int32_t* seg_widths, int32_t nseg, void* pack,
+                             size_t pack_bytes, int32_t* ovf, void* stream);
+/* u [rows_pad, ldu] = cat(x...) W^T + bias (+ residual): the pre-activation, which the backward needs. */
+int fc_train_linear_fwd_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* const* x, const int32_t* ldx,
+                            int32_t rows_pad, const float* residual, int32_t ldr, float* u, int32_t ldu, int32_t* ovf, void* stream);
+/* dx [rows_pad, lddx >= sum of padded segment widths] = du W  (columns in padded-segment order). */
+int fc_train_linear_dgrad_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu,
+                              int32_t rows_pad, float* dx, int32_t lddx, int32_t* ovf, void* stream);
+size_t fc_train_linear_wgrad_ws_bytes(int32_t N, const int32_t* seg_widths, int32_t nseg, int32_t rows);
+/* dW [N,K] (=|+=) du[:rows]^T cat(x...)[:rows],  db [N] (=|+=) column sums of du[:rows]; either may be NULL.  fp32-input MFMA,
+ * fixed summation order (bit-reproducible).  ws: 256-byte aligned scratch of fc_train_linear_wgrad_ws_bytes. */
+int fc_train_linear_wgrad_f32(int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu, const float* const* x,
+                              const int32_t* ldx, int32_t rows, float* dW, float* db, int32_t accumulate, void* ws, size_t ws_bytes,
+                              void* stream);
+/* y = act(u) and du = dy * act'(u) on dense [rows_pad, ld] panels (enum fc_act; GELU is the exact erf form);
+ * rows >= `rows` of du are written as zeros. */
+int fc_train_act_fwd_f32(const float* u, float* y, int32_t rows_pad, int32_t ld, int32_t act, void* stream);
+int fc_train_act_bwd_f32(const float* dy, const float* u, float* du, int32_t rows_pad, int32_t rows, int32_t ld, int32_t act, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,121 @@
+"""Training primitives (first slice: the residual MLP of models/nets.py:19-30): HIP forward AND backward
+through the C ABI (fc_train_*), against fp64 autograd of the pinned oracle's `mlp` / plain fp64 torch on the host."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import flowcompare_amd as fa
+from flowcompare_amd import modules as M
+from flowcompare_amd import train_ops as T
+from oracle import flow_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return (a.double().cpu() - b).abs().max().item() / max(1e-30, b.abs().max().item())
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+@pytest.mark.parametrize("rows,widths,N,act,res", [(300, [150, 512], 512, "GELU", True), (1000, [150], 256, "RELU", False),
+                                                   (257, [70, 33, 1], 300, None, False), (4096, [512], 3750, "ELU", False)])
+def test_linear_act_forward_and_backward_match_fp64(rows, widths, N, act, res, fp16):
+    g = torch.Generator().manual_seed(rows + N)
+    K = sum(widths)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).double().requires_grad_(True)
+    b = (torch.randn(N, generator=g) * 0.3).double().requires_grad_(True)
+    xs = [torch.randn(rows, w, generator=g).double().requires_grad_(True) for w in widths]
+    r = torch.randn(rows, N, generator=g).double().requires_grad_(True) if res else None
+    dy = torch.randn(rows, N, generator=g).double()
+    u = F.linear(torch.cat(xs, -1), W, b) + (r if res else 0)
+    y = {"GELU": F.gelu, "RELU": F.relu, "ELU": F.elu, None: lambda t: t}[act](u)
+    y.backward(dy)
+
+    Wd, bd = W.detach().float().to(DEV).requires_grad_(True), b.detach().float().to(DEV).requires_grad_(True)
+    xd = [x.detach().float().to(DEV).requires_grad_(True) for x in xs]
+    rd = r.detach().float().to(DEV).requires_grad_(True) if res else None
+    with T.step_guard(fp16=fp16, device=DEV) as guard:
+        yp = T.linear_act([T.to_panel(x) for x in xd], widths, Wd, bd, rows, act, residual=None if rd is None else T.to_panel(rd))
+        out = T.from_panel(yp, rows, N)
+        out.backward(dy.float().to(DEV))
+        assert not guard.overflowed()
+    errs = dict(y=_rel(out.detach(), y.detach()), dW=_rel(Wd.grad, W.grad), db=_rel(bd.grad, b.grad))
+    for i, (a, c) in enumerate(zip(xd, xs)):
+        errs[f"dx{i}"] = _rel(a.grad, c.grad)
+    if res:
+        errs["dres"] = _rel(rd.grad, r.grad)
+    print(f"rows {rows} widths {widths} N {N} act {act} fp16 {fp16}: " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    assert max(errs.values()) < 5e-6, errs
+    assert yp[:, N:].abs().sum().item() == 0.0                              # pad columns stay zero (zero weights and bias, act(0) = 0)
+
+
+def test_weight_gradient_is_bit_reproducible_and_ignores_pad_rows():
+    g = torch.Generator().manual_seed(5)
+    rows, K, N = 1000, 150, 256
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.zeros(N, device=DEV, requires_grad=True)
+    x = T.to_panel(torch.randn(rows, K, generator=g).to(DEV))
+    grads = []
+    for junk in (0.0, 7.0):
+        dy = torch.randn(x.shape[0], N, generator=torch.Generator().manual_seed(6)).to(DEV)
+        dy[rows:] = dy[rows:] * junk + junk                            # rows beyond `rows` must never reach dW / db
+        W.grad = b.grad = None
+        y = T.linear_act([x], [K], W, b, rows, None)
+        y.backward(dy)
+        grads.append((W.grad.clone(), b.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
+@pytest.mark.parametrize("act", ["GELU", "RELU"])
+def test_mlp_at_coupling_widths_matches_oracle_autograd(act):
+    """The coupling network of a C2 layer (cat(x1 150, attention 512) -> 512^3 -> 300, models/affine_coupling.py:33) on two panels:
+    outputs and gradients of every parameter and both inputs against fp64 autograd through the pinned oracle's mlp()."""
+    torch.manual_seed(3)
+    mlp = M.MLP(662, [512, 512, 512], 300).to(DEV)
+    rows = 700
+    g = torch.Generator().manual_seed(4)
+    x1, c = torch.randn(rows, 150, generator=g), torch.randn(rows, 512, generator=g)
+    dy = torch.randn(rows, 300, generator=g)
+    sd = {("m." + k): v.detach().cpu().double().requires_grad_(True) for k, v in mlp.state_dict().items()}
+    x1o, co = x1.double().requires_grad_(True), c.double().requires_grad_(True)
+    yo = O.mlp(sd, "m", torch.cat((x1o, co), -1), O._act(act))
+    yo.backward(dy.double())
+
+    x1d, cd = x1.to(DEV).requires_grad_(True), c.to(DEV).requires_grad_(True)
+    with T.step_guard(device=DEV) as guard:
+        yp = T.mlp_panels(mlp, [T.to_panel(x1d), T.to_panel(cd)], [150, 512], rows, act)
+        y = T.from_panel(yp, rows, 300)
+        y.backward(dy.to(DEV))
+        assert not guard.overflowed()
+    errs = dict(y=_rel(y.detach(), yo.detach()), dx1=_rel(x1d.grad, x1o.grad), dc=_rel(cd.grad, co.grad))
+    for k, p in mlp.named_parameters():
+        errs["d" + k] = _rel(p.grad, sd["m." + k].grad)
+    print(f"MLP 150|512 -> 512^3 -> 300, {act}: " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()))
+    assert max(errs.values()) < 2e-5, errs
+
+
+def test_mlp_forward_on_plain_tensors_and_range_guard():
+    torch.manual_seed(8)
+    mlp = M.MLP(6, [64, 64, 64], 32).to(DEV)
+    x = torch.randn(2, 50, 6, device=DEV, requires_grad=True)
+    with T.step_guard(device=DEV) as guard:
+        y = T.mlp_forward(mlp, x, "GELU")
+        y.sum().backward()
+        assert not guard.overflowed()
+    sd = {("m." + k): v.detach().cpu().double() for k, v in mlp.state_dict().items()}
+    assert y.shape == (2, 50, 32) and _rel(y.detach(), O.mlp(sd, "m", x.detach().cpu().double(), F.gelu)) < 5e-6
+    ref = mlp.in_layer.weight.grad.clone()
+    # outside the fp16 range the flag comes back set; the fp32-input loop then gives the answer
+    big = (x.detach() * 1e5).requires_grad_(True)
+    with T.step_guard(device=DEV) as guard:
+        T.mlp_forward(mlp, big, "RELU").sum().backward()
+        assert guard.overflowed()
+    mlp.zero_grad()
+    with T.step_guard(fp16=False, device=DEV) as guard:
+        y32 = T.mlp_forward(mlp, big, "RELU")
+        y32.sum().backward()
+        assert not guard.overflowed()
+    want = O.mlp(sd, "m", big.detach().cpu().double(), F.relu)
+    assert _rel(y32.detach(), want) < 5e-6
+    assert torch.isfinite(mlp.in_layer.weight.grad).all() and ref.shape == mlp.in_layer.weight.grad.shape
