@@ -533,6 +533,12 @@ void launch_attention_c16(const float* q, int ldq, const unsigned short* kv_c16,
     launch_attention_scaled(q, ldq, nullptr, 4, nullptr, 4, out, ldo, B, N, n_stride_rows, M, m_stride_rows, dh_pad, 1.0f, nullptr, s, kp, vp, n_pad / 4, lnq);
 }
 
+// training path (train_attention.hip): strided q / k / v (columns of wider panels), explicit softmax scale
+void launch_attention_scaled_op(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int N, int M,
+                                int dh_pad, float scale, void* limb_ws, hipStream_t s) {
+    launch_attention_scaled(q, ldq, k, ldk, v, ldv, out, ldo, B, N, N, M, M, dh_pad, scale * 1.4426950408889634f, limb_ws, s);
+}
+
 void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale,
                          void* limb_ws, hipStream_t s) {
     launch_attention_scaled(q, dh_pad, k, dh_pad, v, dh_pad, out, dh_pad, B, N, N, M, M, dh_pad,

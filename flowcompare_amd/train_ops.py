@@ -200,3 +200,45 @@ def mlp_forward(mlp, x, act="GELU"):
     rows = x2.shape[0]
     y = mlp_panels(mlp, [to_panel(x2)], [x2.shape[1]], rows, act)
     return from_panel(y, rows, mlp.out_layer.out_features).reshape(*lead, -1)
+
+
+class AttentionFn(torch.autograd.Function):
+    """out = softmax(q k^T scale) v per scene (models/perceiver.py:106-113) on panels q [B*N (padded), D], k / v [B*M (padded), D];
+    D = head dim padded to 32 or 64 with zero columns.  Backward recomputes the scores tile by tile (csrc/train_attention.hip)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B, N, M, scale):
+        L = engine.lib()
+        D = q.shape[1]
+        for t, rows in ((q, B * N), (k, B * M), (v, B * M)):
+            _check_panel(t, D)
+            if t.shape[0] < rows or t.shape[1] != D:
+                raise RuntimeError("AttentionFn: panel smaller than B * points, or head dims differ")
+        dev = q.device
+        out = torch.zeros_like(q)
+        with torch.cuda.device(dev):
+            nb = L.fc_train_attention_ws_bytes(B, N, M, D)
+            ws = _ws(nb, dev) if _Step.flag is not None else None
+            engine._check(L.fc_train_attention_fwd_f32(engine._ptr(q), D, engine._ptr(k), D, engine._ptr(v), D, engine._ptr(out), D, B, N, M, D,
+                                                       ctypes.c_float(scale), engine._ptr(ws), ctypes.c_size_t(nb), _flag_ptr(), engine._stream()))
+        ctx.save_for_backward(q, k, v, out)
+        ctx.meta = (B, N, M, D, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = engine.lib()
+        q, k, v, out = ctx.saved_tensors
+        B, N, M, D, scale = ctx.meta
+        dout = dout.contiguous()
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        stats = torch.empty(2 * B * N, dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            engine._check(L.fc_train_attention_bwd_f32(engine._ptr(q), D, engine._ptr(k), D, engine._ptr(v), D, engine._ptr(out), D,
+                                                       engine._ptr(dout), D, engine._ptr(dq), D, engine._ptr(dk), D, engine._ptr(dv), D,
+                                                       engine._ptr(stats), B, N, M, D, ctypes.c_float(scale), engine._stream()))
+        return dq, dk, dv, None, None, None, None
+
+
+def attention(q, k, v, B, N, M, scale):
+    return AttentionFn.apply(q, k, v, B, N, M, float(scale))

@@ -222,6 +222,17 @@ int fc_train_linear_wgrad_f32(int32_t N, const int32_t* seg_widths, int32_t nseg
 int fc_train_act_fwd_f32(const float* u, float* y, int32_t rows_pad, int32_t ld, int32_t act, void* stream);
 int fc_train_act_bwd_f32(const float* dy, const float* u, float* du, int32_t rows_pad, int32_t rows, int32_t ld, int32_t act, void* stream);
 
+/* Cross-attention core out = softmax(q k^T scale) v per scene (models/perceiver.py:106-113) on row-major matrices with pitches
+ * (q, out, dout, dq: [B*N, ld]; k, v, dk, dv: [B*M, ld]; D = padded head dim, 32 or 64) and its backward, which recomputes the
+ * scores tile by tile (nothing of [N, M] is stored).  fwd: ws (fc_train_attention_ws_bytes) + ovf select the split-fp16 kernel.
+ * bwd: stats = device scratch of 2*B*N floats (log-sum-exp and dO.O per query). */
+size_t fc_train_attention_ws_bytes(int32_t B, int32_t N, int32_t M, int32_t D);
+int fc_train_attention_fwd_f32(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, float* out, int32_t ldo,
+                               int32_t B, int32_t N, int32_t M, int32_t D, float scale, void* ws, size_t ws_bytes, int32_t* ovf, void* stream);
+int fc_train_attention_bwd_f32(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* out,
+                               int32_t ldo, const float* dout, int32_t lddo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv,
+                               int32_t lddv, float* stats, int32_t B, int32_t N, int32_t M, int32_t D, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _rel(a, b):
-    return (a.double().cpu() - b).abs().max().item() / max(1e-30, b.abs().max().item())
+def _rel(a, b, floor=1e-2):
+    """max |a - b| relative to max |b| (floored: an identically-zero gradient, e.g. q of a one-key softmax, is compared absolutely)."""
+    return (a.double().cpu() - b).abs().max().item() / max(floor, b.abs().max().item())
 
 
 @pytest.mark.parametrize("fp16", [True, False])
@@ -119,3 +120,26 @@ def test_mlp_forward_on_plain_tensors_and_range_guard():
     want = O.mlp(sd, "m", big.detach().cpu().double(), F.relu)
     assert _rel(y32.detach(), want) < 5e-6
     assert torch.isfinite(mlp.in_layer.weight.grad).all() and ref.shape == mlp.in_layer.weight.grad.shape
+
+
+@pytest.mark.parametrize("fp16", [True, False])
+@pytest.mark.parametrize("B,N,M,I", [(2, 300, 77, 64), (3, 130, 1000, 64), (2, 50, 40, 8), (1, 1, 1, 64)])
+def test_attention_forward_and_backward_match_fp64(B, N, M, I, fp16):
+    g = torch.Generator().manual_seed(B * N + M)
+    q = torch.randn(B, N, I, generator=g).double().requires_grad_(True)
+    k = torch.randn(B, M, I, generator=g).double().requires_grad_(True)
+    v = torch.randn(B, M, I, generator=g).double().requires_grad_(True)
+    dout = torch.randn(B, N, I, generator=g).double()
+    scale = I ** -0.5
+    out = torch.softmax(q @ k.transpose(1, 2) * scale, -1) @ v
+    out.backward(dout)
+    qd, kd, vd = (t.detach().float().to(DEV).requires_grad_(True) for t in (q, k, v))
+    with T.step_guard(fp16=fp16, device=DEV) as guard:
+        op = T.attention(T.to_panel(qd.reshape(B * N, I)), T.to_panel(kd.reshape(B * M, I)), T.to_panel(vd.reshape(B * M, I)), B, N, M, scale)
+        o = T.from_panel(op, B * N, I).reshape(B, N, I)
+        o.backward(dout.float().to(DEV))
+        assert not guard.overflowed()
+    # dS = P (dP - dO.O): the difference of two O(|dO| |v| sqrt(I)) sums, so its fp32 error is absolute at that scale (floor 1)
+    errs = dict(out=_rel(o.detach(), out.detach()), dq=_rel(qd.grad, q.grad, 1.0), dk=_rel(kd.grad, k.grad, 1.0), dv=_rel(vd.grad, v.grad))
+    print(f"attention B {B} N {N} M {M} I {I} fp16 {fp16}: " + " ".join(f"{a} {b:.1e}" for a, b in errs.items()))
+    assert max(errs.values()) < 5e-6, errs
