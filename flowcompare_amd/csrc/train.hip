@@ -428,4 +428,25 @@ int fc_train_act_bwd_f32(const float* dy, const float* u, float* du, int32_t row
     FC_API_END
 }
 
+size_t fc_train_colsum_ws_bytes(int32_t cols, int32_t rows) {
+    const int S = std::max(1, std::min(256, rows / 256));
+    return (size_t)S * round_up(std::max(cols, 1), 32) * 4 + 256;
+}
+
+/* out[c] (=|+=) sum over rows [0, rows) of a[row][c], fixed summation order */
+int fc_train_colsum_f32(const float* a, int32_t lda, int32_t cols, int32_t rows, float* out, int32_t accumulate, void* ws, size_t ws_bytes,
+                        void* stream) {
+    FC_API_BEGIN
+    if (!a || !out || cols < 1 || rows < 1 || lda < cols) throw Error(FC_ERR_INVALID, "fc_train_colsum_f32: bad argument");
+    if (!ws || ws_bytes < fc_train_colsum_ws_bytes(cols, rows)) throw Error(FC_ERR_WORKSPACE, "fc_train_colsum_f32: workspace too small (fc_train_colsum_ws_bytes)");
+    const int S = std::max(1, std::min(256, rows / 256)), chunk = (rows + S - 1) / S, ld = round_up(cols, 32);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::colsum_kernel", 0.0, (double)rows * cols * 4.0, s);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, S), dim3(256), 0, s, a, lda, cols, rows, chunk, (float*)ws, ld);
+    FC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, (const float*)ws, S, ld, out, cols, accumulate);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
 }  // extern "C"

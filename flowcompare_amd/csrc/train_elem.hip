@@ -1,0 +1,298 @@
+// Row-wise training primitives: rational-quadratic spline coupling element and LayerNorm, forward + backward.
+//   spline   models/spline_coupling.py:24-169 in the REFERENCE's parameter layout: the coupling MLP's output row is [d2][3K+1] =
+//            per transformed dim [K width logits | K height logits | K+1 derivative logits] (spline_coupling.py:196-203).  One
+//            workgroup per point; forward = the inference element function (spline.h), backward = its analytic gradient w.r.t. x and
+//            all 3K+1 logits (through the softmax of the bin widths / heights, the cumulative knots and the softplus derivatives).
+//   layernorm  torch.nn.LayerNorm(width, eps 1e-5) of PreNorm (models/perceiver.py:18-27); backward returns dx and the panel
+//            dy * xhat whose column sums are d gamma (d beta = column sums of dy), reduced by fc_train_colsum_f32 in a fixed order.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "spline.h"
+
+namespace fc {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    // deterministic: xor tree inside each wave, then waves in order
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void spline_train_fwd_kernel(const float* __restrict__ x2, int ldx, const float* __restrict__ params, int ldp,
+                                                               float* __restrict__ y2, int ldy, float* __restrict__ ldj, int d2, int d2_pad) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    float part = 0.f;
+    for (int dim = threadIdx.x; dim < d2_pad; dim += 256) {
+        float y = 0.f, lad = 0.f;
+        if (dim < d2) rq_spline_elem<K>(x2[row * ldx + dim], params + row * ldp + (size_t)dim * (3 * K + 1), 1, false, y, lad);
+        y2[row * ldy + dim] = y;
+        part += lad;
+    }
+    const float s = block_sum_256(part, red);
+    if (threadIdx.x == 0) ldj[row] = s;
+}
+
+// gradient of (y, lad) of ONE spline element: gx = dL/dx, gu[3K+1] = dL/d logits, given gy = dL/dy and gl = dL/dlad
+template <int K>
+__device__ __forceinline__ void rq_spline_bwd_elem(float x, const float* __restrict__ u, float gy, float gl, float& gx, float* __restrict__ gu) {
+    constexpr float B = 3.0f, MINW = 1e-3f, MINH = 1e-3f, MIND = 1e-3f;
+    if (!(x >= -B && x <= B)) {
+        gx = gy;
+#pragma unroll
+        for (int i = 0; i < 3 * K + 1; ++i) gu[i] = 0.f;
+        return;
+    }
+    float pw[K], ph[K], cw[K + 1], ch[K + 1];
+    {
+        float mx = u[0];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { pw[i] = u[i]; mx = fmaxf(mx, pw[i]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { pw[i] = expf(pw[i] - mx); sum += pw[i]; }
+        float c = 0.f;
+        cw[0] = -B;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { pw[i] = pw[i] / sum; c += MINW + (1.0f - MINW * K) * pw[i]; cw[i + 1] = 2.0f * B * c - B; }
+        cw[K] = B;
+    }
+    {
+        float mx = u[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { ph[i] = u[K + i]; mx = fmaxf(mx, ph[i]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { ph[i] = expf(ph[i] - mx); sum += ph[i]; }
+        float c = 0.f;
+        ch[0] = -B;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { ph[i] = ph[i] / sum; c += MINH + (1.0f - MINH * K) * ph[i]; ch[i + 1] = 2.0f * B * c - B; }
+        ch[K] = B;
+    }
+    int bin = 0;
+#pragma unroll
+    for (int i = 1; i <= K; ++i) bin += (x >= cw[i] + (i == K ? 1e-6f : 0.f)) ? 1 : 0;
+    float in_cw = cw[0], w = cw[1] - cw[0], in_ch = ch[0], h = ch[1] - ch[0];
+    float raw0 = -1e-3f, raw1 = u[2 * K];
+#pragma unroll
+    for (int i = 1; i < K; ++i)
+        if (bin == i) { in_cw = cw[i]; w = cw[i + 1] - cw[i]; in_ch = ch[i]; h = ch[i + 1] - ch[i]; raw0 = u[2 * K + i - 1]; raw1 = u[2 * K + i]; }
+    auto softplus = [](float v) { return v > 20.f ? v : log1pf(expf(v)); };
+    auto sigmoid = [](float v) { return 1.0f / (1.0f + expf(-v)); };
+    const float d0 = MIND + softplus(raw0), d1 = MIND + softplus(raw1);
+    const float s = h / w;
+    const float th = (x - in_cw) / w, omt = 1.0f - th, tt = th * omt;
+    const float A = s * th * th + d0 * tt;
+    const float E = d0 + d1 - 2.0f * s;
+    const float den = s + E * tt;
+    const float G = d1 * th * th + 2.0f * s * tt + d0 * omt * omt;
+    const float rden = 1.0f / den, rG = 1.0f / G;
+    const float dtt = 1.0f - 2.0f * th;
+    // y = ch + h A / den ; lad = 2 log s + log G - 2 log den
+    const float y_A = h * rden, y_den = -h * A * rden * rden;
+    const float g_th = gy * (y_A * (2.0f * s * th + d0 * dtt) + y_den * (E * dtt)) +
+                       gl * ((2.0f * d1 * th + 2.0f * s * dtt - 2.0f * d0 * omt) * rG - 2.0f * E * dtt * rden);
+    const float g_s = gy * (y_A * th * th + y_den * (1.0f - 2.0f * tt)) + gl * (2.0f / s + 2.0f * tt * rG - 2.0f * (1.0f - 2.0f * tt) * rden);
+    const float g_d0 = gy * (y_A * tt + y_den * tt) + gl * (omt * omt * rG - 2.0f * tt * rden);
+    const float g_d1 = gy * (y_den * tt) + gl * (th * th * rG - 2.0f * tt * rden);
+    const float g_h = gy * A * rden + g_s / w;                              // direct + through s = h / w
+    const float g_w = -g_s * s / w - g_th * th / w;                         // through s and through th = (x - cw) / w
+    const float g_cw = -g_th / w;
+    gx = g_th / w;
+    // widths: bin b owns w_b = 2B p_b and its left knot cw_b = -B + sum_{k<b} w_k ; p = MIN + (1 - K MIN) softmax(u)
+    {
+        float gs[K], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float gwk = (k < bin ? g_cw : 0.f) + (k == bin ? g_w : 0.f);
+            gs[k] = 2.0f * B * (1.0f - MINW * K) * gwk;
+            dot += pw[k] * gs[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) gu[k] = pw[k] * (gs[k] - dot);
+    }
+    {
+        float gs[K], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float ghk = (k < bin ? gy : 0.f) + (k == bin ? g_h : 0.f);       // d y / d ch_b = 1
+            gs[k] = 2.0f * B * (1.0f - MINH * K) * ghk;
+            dot += ph[k] * gs[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) gu[K + k] = ph[k] * (gs[k] - dot);
+    }
+    // derivative logits: knot j >= 1 uses logit j-1 (knot 0 is the padded constant, the last logit is never read)
+    const float gr0 = g_d0 * sigmoid(raw0), gr1 = g_d1 * sigmoid(raw1);
+#pragma unroll
+    for (int j = 0; j <= K; ++j) gu[2 * K + j] = (j == bin - 1 ? gr0 : 0.f) + (j == bin ? gr1 : 0.f);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void spline_train_bwd_kernel(const float* __restrict__ x2, int ldx, const float* __restrict__ params, int ldp,
+                                                               const float* __restrict__ dy2, int lddy, const float* __restrict__ dldj,
+                                                               float* __restrict__ dx2, int lddx, float* __restrict__ dparams, int lddp, int d2,
+                                                               int d2_pad, int np_pad) {
+    const size_t row = blockIdx.x;
+    const float gl = dldj[row];
+    for (int dim = threadIdx.x; dim < d2_pad; dim += 256) {
+        float gx = 0.f;
+        if (dim < d2) {
+            float gu[3 * K + 1];
+            rq_spline_bwd_elem<K>(x2[row * ldx + dim], params + row * ldp + (size_t)dim * (3 * K + 1), dy2[row * lddy + dim], gl, gx, gu);
+            float* dst = dparams + row * lddp + (size_t)dim * (3 * K + 1);
+#pragma unroll
+            for (int i = 0; i < 3 * K + 1; ++i) dst[i] = gu[i];
+        }
+        dx2[row * lddx + dim] = gx;
+    }
+    for (int c = d2 * (3 * K + 1) + threadIdx.x; c < np_pad; c += 256) dparams[row * lddp + c] = 0.f;
+}
+
+// ---------------------------------------------------------------- LayerNorm: one wave per row
+__global__ __launch_bounds__(256) void layernorm_train_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ y, int ldy,
+                                                                  float* __restrict__ stats, int rows, int width, int width_pad, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int c = lane; c < width; c += 64) s += xr[c];
+    for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+    const float mean = s / width;
+    float v = 0.f;
+    for (int c = lane; c < width; c += 64) { const float d = xr[c] - mean; v += d * d; }
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    const float rstd = 1.0f / sqrtf(v / width + eps);
+    for (int c = lane; c < width_pad; c += 64) y[(size_t)row * ldy + c] = c < width ? (xr[c] - mean) * rstd * gamma[c] + beta[c] : 0.f;
+    if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+}
+
+// dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma ; t = dy xhat (column sums = d gamma)
+__global__ __launch_bounds__(256) void layernorm_train_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ dy, int lddy, const float* __restrict__ stats,
+                                                                  float* __restrict__ dx, int lddx, float* __restrict__ t, int ldt, int rows,
+                                                                  int rows_pad, int width, int width_pad) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows_pad) return;
+    if (row >= rows) {
+        for (int c = lane; c < width_pad; c += 64) { dx[(size_t)row * lddx + c] = 0.f; t[(size_t)row * ldt + c] = 0.f; }
+        return;
+    }
+    const float mean = stats[2 * (size_t)row], rstd = stats[2 * (size_t)row + 1];
+    const float* xr = x + (size_t)row * ldx;
+    const float* gr = dy + (size_t)row * lddy;
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < width; c += 64) {
+        const float g = gr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+        a += g; b += g * xh;
+    }
+    for (int m = 1; m < 64; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+    a /= width; b /= width;
+    for (int c = lane; c < width_pad; c += 64) {
+        float o = 0.f, tv = 0.f;
+        if (c < width) {
+            const float xh = (xr[c] - mean) * rstd;
+            o = rstd * (gr[c] * gamma[c] - a - xh * b);
+            tv = gr[c] * xh;
+        }
+        dx[(size_t)row * lddx + c] = o;
+        t[(size_t)row * ldt + c] = tv;
+    }
+}
+
+template <int K>
+static void spline_fwd_k(const float* x2, int ldx, const float* params, int ldp, float* y2, int ldy, float* ldj, int rows, int d2, hipStream_t s) {
+    ProfScope ps("fc::spline_train_fwd_kernel", 0.0, (double)rows * d2 * (3 * K + 3) * 4.0, s);
+    hipLaunchKernelGGL(spline_train_fwd_kernel<K>, dim3(rows), dim3(256), 0, s, x2, ldx, params, ldp, y2, ldy, ldj, d2, round_up(d2, 32));
+    FC_HIP(hipGetLastError());
+}
+template <int K>
+static void spline_bwd_k(const float* x2, int ldx, const float* params, int ldp, const float* dy2, int lddy, const float* dldj, float* dx2, int lddx,
+                         float* dparams, int lddp, int rows, int d2, hipStream_t s) {
+    ProfScope ps("fc::spline_train_bwd_kernel", 0.0, (double)rows * d2 * (6 * K + 5) * 4.0, s);
+    hipLaunchKernelGGL(spline_train_bwd_kernel<K>, dim3(rows), dim3(256), 0, s, x2, ldx, params, ldp, dy2, lddy, dldj, dx2, lddx, dparams, lddp, d2,
+                       round_up(d2, 32), round_up(d2 * (3 * K + 1), 32));
+    FC_HIP(hipGetLastError());
+}
+
+}  // namespace fc
+
+using namespace fc;
+
+#define FC_API_BEGIN try {
+#define FC_API_END                                                                            \
+    }                                                                                         \
+    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }               \
+    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; }  \
+    return FC_OK;
+
+extern "C" {
+
+int fc_train_rqspline_fwd_f32(const float* x2, int32_t ldx, const float* params, int32_t ldp, float* y2, int32_t ldy, float* ldj, int32_t rows,
+                              int32_t d2, int32_t K, void* stream) {
+    FC_API_BEGIN
+    if (!x2 || !params || !y2 || !ldj || rows < 1 || d2 < 1 || ldx < d2 || ldy < round_up(d2, 32) || ldp < d2 * (3 * K + 1))
+        throw Error(FC_ERR_INVALID, "fc_train_rqspline_fwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    switch (K) {
+        case 4: spline_fwd_k<4>(x2, ldx, params, ldp, y2, ldy, ldj, rows, d2, s); break;
+        case 8: spline_fwd_k<8>(x2, ldx, params, ldp, y2, ldy, ldj, rows, d2, s); break;
+        case 16: spline_fwd_k<16>(x2, ldx, params, ldp, y2, ldy, ldj, rows, d2, s); break;
+        default: throw Error(FC_ERR_UNSUPPORTED, "fc_train_rqspline_fwd_f32: num_bins must be 4, 8 or 16");
+    }
+    FC_API_END
+}
+
+int fc_train_rqspline_bwd_f32(const float* x2, int32_t ldx, const float* params, int32_t ldp, const float* dy2, int32_t lddy, const float* dldj,
+                              float* dx2, int32_t lddx, float* dparams, int32_t lddp, int32_t rows, int32_t d2, int32_t K, void* stream) {
+    FC_API_BEGIN
+    if (!x2 || !params || !dy2 || !dldj || !dx2 || !dparams || rows < 1 || d2 < 1 || ldx < d2 || lddy < d2 || lddx < round_up(d2, 32) ||
+        ldp < d2 * (3 * K + 1) || lddp < round_up(d2 * (3 * K + 1), 32))
+        throw Error(FC_ERR_INVALID, "fc_train_rqspline_bwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    switch (K) {
+        case 4: spline_bwd_k<4>(x2, ldx, params, ldp, dy2, lddy, dldj, dx2, lddx, dparams, lddp, rows, d2, s); break;
+        case 8: spline_bwd_k<8>(x2, ldx, params, ldp, dy2, lddy, dldj, dx2, lddx, dparams, lddp, rows, d2, s); break;
+        case 16: spline_bwd_k<16>(x2, ldx, params, ldp, dy2, lddy, dldj, dx2, lddx, dparams, lddp, rows, d2, s); break;
+        default: throw Error(FC_ERR_UNSUPPORTED, "fc_train_rqspline_bwd_f32: num_bins must be 4, 8 or 16");
+    }
+    FC_API_END
+}
+
+int fc_train_layernorm_fwd_f32(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy, float* stats,
+                               int32_t rows, int32_t width, float eps, void* stream) {
+    FC_API_BEGIN
+    if (!x || !gamma || !beta || !y || !stats || rows < 1 || width < 1 || ldx < width || ldy < round_up(width, 32))
+        throw Error(FC_ERR_INVALID, "fc_train_layernorm_fwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::layernorm_train_fwd_kernel", 0.0, (double)rows * width * 8.0, s);
+    hipLaunchKernelGGL(layernorm_train_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, stats, rows, width,
+                       round_up(width, 32), eps);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_layernorm_bwd_f32(const float* x, int32_t ldx, const float* gamma, const float* dy, int32_t lddy, const float* stats, float* dx,
+                               int32_t lddx, float* dy_xhat, int32_t ldt, int32_t rows_pad, int32_t rows, int32_t width, void* stream) {
+    FC_API_BEGIN
+    if (!x || !gamma || !dy || !stats || !dx || !dy_xhat || rows < 1 || rows_pad < rows || width < 1 || ldx < width || lddy < width ||
+        lddx < round_up(width, 32) || ldt < round_up(width, 32))
+        throw Error(FC_ERR_INVALID, "fc_train_layernorm_bwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::layernorm_train_bwd_kernel", 0.0, (double)rows * width * 16.0, s);
+    hipLaunchKernelGGL(layernorm_train_bwd_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, s, x, ldx, gamma, dy, lddy, stats, dx, lddx, dy_xhat, ldt,
+                       rows, rows_pad, width, round_up(width, 32));
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+}  // extern "C"

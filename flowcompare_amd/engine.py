@@ -31,6 +31,8 @@ EXPORTS = [
     "fc_train_linear_pack_bytes", "fc_train_linear_pack_f32", "fc_train_linear_fwd_f32", "fc_train_linear_dgrad_f32",
     "fc_train_linear_wgrad_ws_bytes", "fc_train_linear_wgrad_f32", "fc_train_act_fwd_f32", "fc_train_act_bwd_f32",
     "fc_train_attention_ws_bytes", "fc_train_attention_fwd_f32", "fc_train_attention_bwd_f32",
+    "fc_train_rqspline_fwd_f32", "fc_train_rqspline_bwd_f32", "fc_train_layernorm_fwd_f32", "fc_train_layernorm_bwd_f32",
+    "fc_train_colsum_ws_bytes", "fc_train_colsum_f32",
 ]
 
 
@@ -69,6 +71,7 @@ def lib():
         L.fc_train_linear_pack_bytes.restype = ctypes.c_size_t
         L.fc_train_linear_wgrad_ws_bytes.restype = ctypes.c_size_t
         L.fc_train_attention_ws_bytes.restype = ctypes.c_size_t
+        L.fc_train_colsum_ws_bytes.restype = ctypes.c_size_t
         if L.fc_abi_version() != ABI_VERSION:
             raise RuntimeError("libfcflow.so ABI version mismatch: rebuild with `python -m flowcompare_amd.build --force`")
         _lib = L

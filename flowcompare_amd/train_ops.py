@@ -242,3 +242,90 @@ class AttentionFn(torch.autograd.Function):
 
 def attention(q, k, v, B, N, M, scale):
     return AttentionFn.apply(q, k, v, B, N, M, float(scale))
+
+
+class SplineFn(torch.autograd.Function):
+    """Rational-quadratic spline coupling element (models/spline_coupling.py:24-169), reference parameter layout.
+    x2 panel [rows_pad, round_up(d2, 32)], params panel [rows_pad, round_up(d2 (3K+1), 32)] -> (y2 panel, ldj [rows_pad])."""
+
+    @staticmethod
+    def forward(ctx, x2, params, rows, d2, K):
+        L = engine.lib()
+        _check_panel(x2, d2)
+        _check_panel(params, d2 * (3 * K + 1))
+        y2 = torch.zeros_like(x2)
+        ldj = torch.zeros(x2.shape[0], dtype=torch.float32, device=x2.device)
+        with torch.cuda.device(x2.device):
+            engine._check(L.fc_train_rqspline_fwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(params), params.shape[1], engine._ptr(y2),
+                                                      y2.shape[1], engine._ptr(ldj), rows, d2, K, engine._stream()))
+        ctx.save_for_backward(x2, params)
+        ctx.meta = (rows, d2, K)
+        return y2, ldj
+
+    @staticmethod
+    def backward(ctx, dy2, dldj):
+        L = engine.lib()
+        x2, params = ctx.saved_tensors
+        rows, d2, K = ctx.meta
+        dy2, dldj = dy2.contiguous(), dldj.contiguous()
+        dx2, dparams = torch.zeros_like(x2), torch.zeros_like(params)
+        with torch.cuda.device(x2.device):
+            engine._check(L.fc_train_rqspline_bwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(params), params.shape[1], engine._ptr(dy2),
+                                                      dy2.shape[1], engine._ptr(dldj), engine._ptr(dx2), dx2.shape[1], engine._ptr(dparams),
+                                                      dparams.shape[1], rows, d2, K, engine._stream()))
+        return dx2, dparams, None, None, None
+
+
+def rq_spline(x2, params, rows, d2, K):
+    return SplineFn.apply(x2, params, rows, d2, K)
+
+
+def _colsum(a, cols, rows):
+    L = engine.lib()
+    out = torch.empty(cols, dtype=torch.float32, device=a.device)
+    nb = L.fc_train_colsum_ws_bytes(cols, rows)
+    ws = _ws(nb, a.device)
+    engine._check(L.fc_train_colsum_f32(engine._ptr(a), a.shape[1], cols, rows, engine._ptr(out), 0, engine._ptr(ws), ctypes.c_size_t(nb),
+                                        engine._stream()))
+    return out
+
+
+class LayerNormFn(torch.autograd.Function):
+    """torch.nn.LayerNorm(width) (PreNorm, models/perceiver.py:18-27) on a panel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rows, eps):
+        L = engine.lib()
+        width = gamma.shape[0]
+        _check_panel(x, width)
+        y = torch.zeros(x.shape[0], _round_up(width, 32), dtype=torch.float32, device=x.device)
+        stats = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        with torch.cuda.device(x.device):
+            engine._check(L.fc_train_layernorm_fwd_f32(engine._ptr(x), x.shape[1], engine._ptr(g32), engine._ptr(b32), engine._ptr(y), y.shape[1],
+                                                       engine._ptr(stats), rows, width, ctypes.c_float(eps), engine._stream()))
+        ctx.save_for_backward(x, g32, stats)
+        ctx.meta = (rows, width, gamma.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = engine.lib()
+        x, g32, stats = ctx.saved_tensors
+        rows, width, pdtype = ctx.meta
+        dy = dy.contiguous()
+        wp = _round_up(width, 32)
+        dx = torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
+        if x.shape[1] != wp:
+            dx.zero_()
+        t = torch.empty(x.shape[0], wp, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            engine._check(L.fc_train_layernorm_bwd_f32(engine._ptr(x), x.shape[1], engine._ptr(g32), engine._ptr(dy), dy.shape[1], engine._ptr(stats),
+                                                       engine._ptr(dx), dx.shape[1], engine._ptr(t), wp, x.shape[0], rows, width, engine._stream()))
+            dgamma = _colsum(t, width, rows).to(pdtype)
+            dbeta = _colsum(dy, width, rows).to(pdtype)
+        return dx, dgamma, dbeta, None, None
+
+
+def layer_norm(x, gamma, beta, rows, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, rows, eps)

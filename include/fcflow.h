@@ -233,6 +233,23 @@ int fc_train_attention_bwd_f32(const float* q, int32_t ldq, const float* k, int3
                                int32_t ldo, const float* dout, int32_t lddo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv,
                                int32_t lddv, float* stats, int32_t B, int32_t N, int32_t M, int32_t D, float scale, void* stream);
 
+/* Rational-quadratic spline coupling element in the reference's parameter layout (models/spline_coupling.py:187-210: the coupling
+ * MLP's output row is [d2][K width | K height | K+1 derivative logits]), forward (y2, ldj[row] = sum over dims of log|dy/dx|) and
+ * the analytic backward w.r.t. x2 and every logit.  Pad columns of y2 / dx2 / dparams are written as zeros. */
+int fc_train_rqspline_fwd_f32(const float* x2, int32_t ldx, const float* params, int32_t ldp, float* y2, int32_t ldy, float* ldj, int32_t rows,
+                              int32_t d2, int32_t K, void* stream);
+int fc_train_rqspline_bwd_f32(const float* x2, int32_t ldx, const float* params, int32_t ldp, const float* dy2, int32_t lddy, const float* dldj,
+                              float* dx2, int32_t lddx, float* dparams, int32_t lddp, int32_t rows, int32_t d2, int32_t K, void* stream);
+/* torch.nn.LayerNorm(width) of PreNorm (models/perceiver.py:18-27).  stats [2*rows] = (mean, rstd) per row, kept for the backward;
+ * bwd writes dx and the panel dy*xhat, whose column sums are d gamma (d beta = column sums of dy): fc_train_colsum_f32. */
+int fc_train_layernorm_fwd_f32(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy, float* stats,
+                               int32_t rows, int32_t width, float eps, void* stream);
+int fc_train_layernorm_bwd_f32(const float* x, int32_t ldx, const float* gamma, const float* dy, int32_t lddy, const float* stats, float* dx,
+                               int32_t lddx, float* dy_xhat, int32_t ldt, int32_t rows_pad, int32_t rows, int32_t width, void* stream);
+size_t fc_train_colsum_ws_bytes(int32_t cols, int32_t rows);
+int fc_train_colsum_f32(const float* a, int32_t lda, int32_t cols, int32_t rows, float* out, int32_t accumulate, void* ws, size_t ws_bytes,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,54 @@ def test_attention_forward_and_backward_match_fp64(B, N, M, I, fp16):
     errs = dict(out=_rel(o.detach(), out.detach()), dq=_rel(qd.grad, q.grad, 1.0), dk=_rel(kd.grad, k.grad, 1.0), dv=_rel(vd.grad, v.grad))
     print(f"attention B {B} N {N} M {M} I {I} fp16 {fp16}: " + " ".join(f"{a} {b:.1e}" for a, b in errs.items()))
     assert max(errs.values()) < 5e-6, errs
+
+
+@pytest.mark.parametrize("spread", [0.5, 1.5])
+@pytest.mark.parametrize("K,d2,rows", [(8, 150, 300), (4, 6, 70), (16, 33, 257)])
+def test_spline_forward_and_backward_match_oracle_autograd(K, d2, rows, spread):
+    """The training spline element against fp64 autograd through the pinned oracle's rq_spline (reference layout [d2][3K+1]);
+    inputs cover the tails (|x| > 3: identity, zero parameter gradient), every bin and the +bound knot.  With widely spread logits
+    (1.5) some bins are ~0.01 wide with slopes of several hundred, where fp32 itself is ill-conditioned (knot rounding times slope):
+    there the gate is the error of the SAME oracle run in fp32 (eager PyTorch, i.e. what the reference's own training computes)."""
+    g = torch.Generator().manual_seed(K + d2)
+    x = (torch.rand(rows, d2, generator=g) * 8 - 4).double()
+    x[0, :3] = torch.tensor([-3.0, 3.0, 0.0], dtype=torch.float64)
+    p = (torch.randn(rows, d2, 3 * K + 1, generator=g) * spread).double()
+    gy, gl = torch.randn(rows, d2, generator=g).double(), torch.randn(rows, generator=g).double()
+
+    def oracle(dtype):
+        xx, pp = x.detach().clone().to(dtype).requires_grad_(True), p.detach().clone().to(dtype).requires_grad_(True)
+        y, lad = O.rq_spline(xx, pp[..., :K], pp[..., K:2 * K], pp[..., 2 * K:])
+        ((y * gy.to(dtype)).sum() + (lad.sum(-1) * gl.to(dtype)).sum()).backward()
+        return y.detach().double(), lad.sum(-1).detach().double(), xx.grad.double(), pp.grad.double()
+    y, ldj64, dx, dp = oracle(torch.float64)
+    y32, ldj32, dx32, dp32 = oracle(torch.float32)
+    xd = x.float().to(DEV).requires_grad_(True)
+    pd = p.float().to(DEV).requires_grad_(True)
+    yp, ldj = T.rq_spline(T.to_panel(xd), T.to_panel(pd.reshape(rows, -1)), rows, d2, K)
+    yy, ll = T.from_panel(yp, rows, d2), ldj[:rows]
+    ((yy * gy.float().to(DEV)).sum() + (ll * gl.float().to(DEV)).sum()).backward()
+    errs = dict(y=_rel(yy.detach(), y), ldj=_rel(ll.detach(), ldj64), dx=_rel(xd.grad, dx), dp=_rel(pd.grad, dp))
+    ref32 = dict(y=_rel(y32, y), ldj=_rel(ldj32, ldj64), dx=_rel(dx32, dx), dp=_rel(dp32, dp))
+    print(f"spline K {K} d2 {d2} rows {rows} spread {spread}: " + " ".join(f"{a} {b:.1e} (fp32 oracle {ref32[a]:.1e})" for a, b in errs.items()))
+    for name in errs:
+        assert errs[name] < 3.0 * ref32[name] + 5e-6, (name, errs[name], ref32[name])
+    assert yp[:, d2:].abs().sum().item() == 0.0
+
+
+@pytest.mark.parametrize("rows,width", [(300, 256), (1000, 8), (5, 100)])
+def test_layernorm_forward_and_backward_match_fp64(rows, width):
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, width, generator=g) * 2 + 0.5).double().requires_grad_(True)
+    gamma = (torch.rand(width, generator=g) + 0.5).double().requires_grad_(True)
+    beta = torch.randn(width, generator=g).double().requires_grad_(True)
+    dy = torch.randn(rows, width, generator=g).double()
+    y = F.layer_norm(x, (width,), gamma, beta, 1e-5)
+    y.backward(dy)
+    xd, gd, bd = (t.detach().float().to(DEV).requires_grad_(True) for t in (x, gamma, beta))
+    yp = T.layer_norm(T.to_panel(xd), gd, bd, rows)
+    yy = T.from_panel(yp, rows, width)
+    yy.backward(dy.float().to(DEV))
+    errs = dict(y=_rel(yy.detach(), y.detach()), dx=_rel(xd.grad, x.grad), dgamma=_rel(gd.grad, gamma.grad), dbeta=_rel(bd.grad, beta.grad))
+    print(f"layernorm rows {rows} width {width}: " + " ".join(f"{a} {b:.1e}" for a, b in errs.items()))
+    assert max(errs.values()) < 5e-6, errs
