@@ -1,0 +1,158 @@
+"""Differentiable `Flow.log_prob` for training: the same transform stack as the inference engine
+(models/transform.py:70-76), assembled from the HIP training primitives of train_ops.py so that `loss.backward()` (train.py:112)
+produces gradients for every flow parameter and for the context embedding.
+
+What runs where
+  * every O(points x features) product or reduction -- the MLPs (nets.py:19-30), LayerNorm, q / k / v / output projections and the
+    softmax attention core (perceiver.py:18-35, 89-115), the spline element (spline_coupling.py:24-169), ActNorm + LinearLU applied as
+    one Linear (act_norm.py:37-43, permuters.py:164-169) -- is a HIP kernel, forward and backward;
+  * parameter-space algebra (building L, U and W = L U diag(exp(-log_scale)) from the LinearLU / ActNorm parameters, 300 x 300) is
+    ordinary differentiable torch on the parameters: torch.autograd carries dW back to lower_entries / upper_entries / log_scale / shift;
+  * the three cheap per-element closures (affine scale-and-shift, the augmenter's reparameterised draw, the base density) are torch
+    elementwise expressions on the HIP tensors in this first cut (DESIGN.md §10 lists them as the next kernels).
+
+Covered: AugmentAttentionPreconditioner or IdentityTransform, PreConditionApplier(CouplingPreconditionerAttn) with
+RationalQuadraticSplineCoupling or AffineCoupling, ActNormBijectionCloud (initialised), LinearLU, extra context.  Not yet: CIFblock,
+the global-context pre-conditioner, ExponentialCoupling and the alternative permuters (they raise NotImplementedError).
+"""
+import math
+
+import torch
+
+from . import modules as M
+from . import train_ops as T
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+def _attention_block(pre, h_panel, h_width, ctx_k, ctx_v, rows, B, N, Mctx):
+    """PreNorm(AttentionControlledOut) on the query side: LayerNorm -> q -> softmax(q k^T I^-1/2) v -> lin."""
+    att = pre.fn.attention
+    inner = att.inner_dim
+    hn = T.layer_norm(h_panel, pre.norm.weight, pre.norm.bias, rows, pre.norm.eps)
+    q = T.linear_act([hn], [h_width], att.to_q.weight, None, rows)
+    a = T.attention(q, ctx_k, ctx_v, B, N, Mctx, inner ** -0.5)
+    return T.linear_act([a], [inner], pre.fn.lin.weight, pre.fn.lin.bias, rows), pre.fn.lin.out_features
+
+
+def _kv(pre, ctx_panel, E, ctx_rows):
+    """K and V projections of the context as two zero-padded panels (to_kv.weight rows [0, I) and [I, 2I))."""
+    att = pre.fn.attention
+    inner = att.inner_dim
+    w = att.to_kv.weight
+    return (T.linear_act([ctx_panel], [E], w[:inner], None, ctx_rows), T.linear_act([ctx_panel], [E], w[inner:], None, ctx_rows))
+
+
+def _lu_weight(perm):
+    """models/permuters.py:148-162: W = L U with unit-lower L and diag(U) = softplus(u) + eps; returns (W, sum log diag)."""
+    D = perm.num_features
+    dev = perm.lower_entries.device
+    diag = torch.nn.functional.softplus(perm.unconstrained_upper_diag) + perm.eps
+    il = torch.tril_indices(D, D, -1, device=dev)
+    iu = torch.triu_indices(D, D, 1, device=dev)
+    L = torch.eye(D, device=dev, dtype=diag.dtype).index_put((il[0], il[1]), perm.lower_entries)
+    U = torch.diag(diag).index_put((iu[0], iu[1]), perm.upper_entries)
+    return L @ U, torch.log(diag).sum()
+
+
+def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None):
+    """log p(x | context) [B, N] with autograd through HIP kernels.  Arguments as Flow.log_prob (modules.py); `eps` pins the
+    augmenter noise.  Call inside train_ops.step_guard() to run the split-fp16 loops with the range flag."""
+    cfg = flow._config
+    act = act or cfg["coupling_block_nonlinearity"]
+    B, N, Din = x.shape
+    D = cfg["latent_dim"]
+    d1 = D // 2
+    d2 = D - d1
+    rows = B * N
+    if cfg.get("global"):
+        raise NotImplementedError("training path: the global-context pre-conditioner is not built yet")
+    Mctx, E = context.shape[1], context.shape[2]
+    ctx_rows = B * Mctx
+    ctx_panel = T.to_panel(context.reshape(ctx_rows, E))
+    X = 0 if extra_context is None else extra_context.shape[-1]
+    extra_panel = None if X == 0 else T.to_panel(extra_context.reshape(rows, X).to(torch.float32))
+    x_panel = T.to_panel(x.reshape(rows, Din))
+    logp = torch.zeros(x_panel.shape[0], dtype=torch.float32, device=x.device)
+    const = torch.zeros((), dtype=torch.float32, device=x.device)
+    eps = list(eps) if eps is not None else None
+    transforms = list(flow.transforms)
+
+    # ---- transform 0: augmenter (models/augmenter.py:15-19, 49-63 + distributions.py:128-153) or identity
+    t0 = transforms[0]
+    if isinstance(t0, M.AugmentAttentionPreconditioner):
+        nz = D - Din
+        k, v = _kv(t0.attn, ctx_panel, E, ctx_rows)
+        h = T.mlp_panels(t0.pre_attn_mlp, [x_panel], [Din], rows, act)
+        a, a_w = _attention_block(t0.attn, h, t0.pre_attn_mlp.out_layer.out_features, k, v, rows, B, N, Mctx)
+        segs, widths = [x_panel], [Din]
+        if X:
+            segs.append(extra_panel); widths.append(X)
+        segs.append(a); widths.append(a_w)
+        p = T.mlp_panels(t0.augment.noise_dist.net, segs, widths, rows, act)
+        mean, log_std = p[:, :nz], p[:, nz:2 * nz]
+        e = eps.pop(0) if eps else torch.randn(B, N, nz, device=x.device)
+        e = torch.nn.functional.pad(e.reshape(rows, nz).to(torch.float32), (0, 0, 0, x_panel.shape[0] - rows))
+        z2 = mean + e * torch.exp(log_std)
+        logp = logp + (0.5 * e * e + log_std + 0.5 * LOG_2PI).sum(-1)            # -log N(z2; mean, std)
+        latent = torch.cat((x_panel[:, :Din], z2), -1)
+    elif isinstance(t0, M.IdentityTransform):
+        latent = x_panel[:, :Din]
+    else:
+        raise NotImplementedError(f"training path: augmenter {type(t0).__name__}")
+    x1 = T.to_panel(latent[:, :d1])
+    x2 = T.to_panel(latent[:, d1:D])
+
+    # ---- layers
+    i = 1
+    while i < len(transforms):
+        blk = transforms[i]
+        if not isinstance(blk, M.PreConditionApplier) or not isinstance(blk.pre_conditioner, M.CouplingPreconditionerAttn):
+            raise NotImplementedError(f"training path: transform {type(blk).__name__} is not built yet (CIFblock / global context)")
+        pc, cp = blk.pre_conditioner, blk.transform
+        k, v = _kv(pc.attn, ctx_panel, E, ctx_rows)
+        h = T.mlp_panels(pc.pre_attention_mlp, [x1], [d1], rows, act)
+        c, c_w = _attention_block(pc.attn, h, pc.pre_attention_mlp.out_layer.out_features, k, v, rows, B, N, Mctx)
+        segs, widths = [x1], [d1]
+        if X:
+            segs.append(extra_panel); widths.append(X)
+        segs.append(c); widths.append(c_w)
+        p = T.mlp_panels(cp.nn, segs, widths, rows, act)
+        if isinstance(cp, M.RationalQuadraticSplineCoupling):
+            x2, ldj = T.rq_spline(x2, p, rows, d2, cp.num_bins)
+            logp = logp + ldj
+        elif isinstance(cp, M.AffineCoupling):
+            raw, t = p[:, :d2], p[:, d2:2 * d2]
+            s = torch.exp(raw) if cp.scale_fn_type == "exp" else (2 * torch.sigmoid(raw) - 1) * (1 - 1e-8) + 1
+            y2 = x2[:, :d2] * s + t
+            logp = logp + torch.log(s).sum(-1)
+            x2 = T.to_panel(y2)
+        else:
+            raise NotImplementedError(f"training path: coupling {type(cp).__name__}")
+        i += 1
+        # ---- ActNorm and the permuter between layers, applied as ONE Linear on (x1 | x2)
+        W, b = None, None
+        if i < len(transforms) and isinstance(transforms[i], M.ActNormBijectionCloud):
+            an = transforms[i]
+            if float(an.initialized.item()) == 0.0:
+                raise NotImplementedError("training path: data-dependent ActNorm initialisation (act_norm.py:27-35) is not built yet; "
+                                          "run one forward through the reference-compatible init or load a checkpoint")
+            g = torch.exp(-an.log_scale.reshape(-1))
+            W, b = torch.diag(g), -an.shift.reshape(-1) * g
+            const = const - an.log_scale.sum()
+            i += 1
+        if i < len(transforms) and isinstance(transforms[i], M.LinearLU):
+            Wlu, logdet = _lu_weight(transforms[i])
+            W, b = (Wlu, None) if W is None else (Wlu @ W, Wlu @ b)
+            const = const + logdet
+            i += 1
+        elif i < len(transforms) and not isinstance(transforms[i], M.PreConditionApplier):
+            raise NotImplementedError(f"training path: permuter {type(transforms[i]).__name__} is not built yet")
+        if W is not None:
+            z1 = T.linear_act([x1, x2], [d1, d2], W[:d1], None if b is None else b[:d1], rows)
+            z2 = T.linear_act([x1, x2], [d1, d2], W[d1:], None if b is None else b[d1:], rows)
+            x1, x2 = z1, z2
+
+    # ---- base density (models/distributions.py:192-195)
+    logp = logp + (-0.5 * (x1 * x1).sum(-1) - 0.5 * (x2 * x2).sum(-1)) - 0.5 * D * LOG_2PI + const
+    return logp[:rows].reshape(B, N)

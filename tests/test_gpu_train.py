@@ -194,3 +194,117 @@ def test_layernorm_forward_and_backward_match_fp64(rows, width):
     errs = dict(y=_rel(yy.detach(), y.detach()), dx=_rel(xd.grad, x.grad), dgamma=_rel(gd.grad, gamma.grad), dbeta=_rel(bd.grad, beta.grad))
     print(f"layernorm rows {rows} width {width}: " + " ".join(f"{a} {b:.1e}" for a, b in errs.items()))
     assert max(errs.values()) < 5e-6, errs
+
+
+# ---------------------------------------------------------------- the whole flow: loss.backward() against the reference's gradients
+import json
+import os
+
+import numpy as np
+
+from conftest import GOLDEN, Fixture
+from flowcompare_amd import train_flow as TF
+import synth
+
+HEAD = 8
+
+
+def _build(fx):
+    cfg = dict(fx.cfg)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    sd_flow, sd_emb = fx.state_dicts()
+    fa.load_flow({"flow": sd_flow, "input_embedder": sd_emb}, md)
+    return cfg, md
+
+
+def _train_step(fx, cfg, md, fp16=True):
+    Din = cfg["input_dim"]
+    e0, e1, ex = fx.t("extract_0").to(DEV), fx.t("extract_1").to(DEV), fx.t("extra")
+    with torch.no_grad():
+        ctx = md["input_embedder"](e0[:, :, :Din])
+    ctx = ctx.detach().requires_grad_(True)
+    x = e1[:, :, :Din].clone().requires_grad_(True)
+    extra = None if ex is None else ex.to(DEV)[:, None, :].expand(-1, e1.shape[1], -1)
+    md["flow"].zero_grad()
+    with T.step_guard(fp16=fp16, device=DEV) as guard:
+        lp = TF.flow_log_prob(md["flow"], x, ctx, extra, [e.to(DEV) for e in fx.eps()])
+        loss = -lp.mean()
+        loss.backward()
+        assert not guard.overflowed()
+    return loss, lp, x, ctx
+
+
+@pytest.mark.parametrize("case", ["tiny_spline_relu", "tiny_affine", "spline_L2"])
+def test_flow_backward_matches_reference_gradients(case):
+    """loss.backward() through the HIP training path against the gradients the REFERENCE produced for the same weights, inputs and
+    noise (tests/golden/grad_*.npz, eval mode): every flow parameter through sum / L1 / random projection / first entries, and
+    d loss / d extract_1."""
+    fx = Fixture("e2e_" + case)
+    z = np.load(os.path.join(GOLDEN, "grad_" + case + ".npz"))
+    cfg, md = _build(fx)
+    loss, lp, x, ctx = _train_step(fx, cfg, md)
+    assert abs(loss.item() - float(z["eval/loss"])) < 2e-4 * max(1.0, abs(float(z["eval/loss"])))
+    assert np.abs(lp.detach().cpu().double().numpy() - fx.a["log_prob_f64"]).max() < 2e-3
+    gnorm = float(z["eval/grad_norm"])
+    dx_err = np.abs(x.grad.cpu().double().numpy() - z["eval/d_extract_1"]).max() / max(1e-12, np.abs(z["eval/d_extract_1"]).max())
+    names = [n for n in json.loads(bytes(z["names_json"]).decode())["eval"] if n.startswith("flow/")]
+    params = dict(md["flow"].named_parameters())
+    # the same step through the pinned oracle in fp32 (eager PyTorch = the arithmetic the reference itself trains in): its distance
+    # from the fp64 reference gradients is the conditioning of the problem, and the yardstick for the HIP path
+    c = fx.derived_cfg()
+    sd32, _ = fx.state_dicts(torch.float32)
+    for v in sd32.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    ex = fx.t("extra", torch.float32)
+    ex = None if ex is None else ex[:, None, :].expand(-1, fx.meta["N"], -1)
+    lp32 = O.flow_log_prob(c, sd32, fx.t("extract_1", torch.float32)[:, :, :c["input_dim"]], ctx.detach().cpu(), ex, fx.eps(torch.float32))
+    (-lp32.mean()).backward()
+
+    def summary(g, key):
+        g = g.double().cpu().reshape(-1)
+        r = torch.from_numpy(synth.normal("gradproj/" + key, (g.numel(),), 0))
+        return np.concatenate([[g.sum().item(), g.abs().sum().item(), (g * r).sum().item()], np.pad(g[:HEAD].numpy(), (0, max(0, HEAD - g.numel())))])
+    worst, worst_name, worst32 = 0.0, "", 0.0
+    for key in names:
+        n = key.split("/", 1)[1]
+        assert params[n].grad is not None, key
+        want = z["eval/" + key]
+        scale = max(want[1], 1e-6 * gnorm)
+        err = np.abs(summary(params[n].grad, key) - want).max() / scale
+        err32 = np.abs(summary(sd32[n].grad, key) - want).max() / scale
+        worst32 = max(worst32, err32)
+        assert err < 1e-3, (key, err, err32)
+        if err > worst:
+            worst, worst_name = err, key
+    print(f"{case}: loss {loss.item():.6f} (ref {float(z['eval/loss']):.6f}); d extract_1 rel err {dx_err:.1e}; {len(names)} flow parameter "
+          f"gradients, worst error / L1 norm {worst:.1e} ({worst_name}); fp32 oracle's worst {worst32:.1e}")
+    assert dx_err < 2e-4 and worst < 3.0 * worst32 + 2e-5
+
+
+def test_flow_backward_with_extra_context_matches_oracle_autograd():
+    """C4 structure at the real widths (dulcet: affine sigmoid coupling, extra z-value context, 3 layers): parameter gradients and the
+    gradient w.r.t. the CONTEXT EMBEDDING (what the embedder's backward will consume) against fp64 autograd through the pinned oracle."""
+    fx = Fixture("e2e_dulcet_L3")
+    cfg, md = _build(fx)
+    loss, lp, x, ctx = _train_step(fx, cfg, md)
+    c = fx.derived_cfg()
+    sd_f, _ = fx.state_dicts(torch.float64)
+    for v in sd_f.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    e1 = fx.t("extract_1", torch.float64)[:, :, :c["input_dim"]].requires_grad_(True)
+    ctx_o = ctx.detach().cpu().double().requires_grad_(True)
+    ex = fx.t("extra", torch.float64)[:, None, :].expand(-1, e1.shape[1], -1)
+    lp_o = O.flow_log_prob(c, sd_f, e1, ctx_o, ex, fx.eps(torch.float64))
+    (-lp_o.mean()).backward()
+    errs = dict(loss=abs(loss.item() + lp_o.mean().item()), dx=_rel(x.grad, e1.grad), dctx=_rel(ctx.grad, ctx_o.grad))
+    worst, worst_name = 0.0, ""
+    for n, p in md["flow"].named_parameters():
+        if sd_f[n].grad is None:
+            continue
+        e = (p.grad.double().cpu() - sd_f[n].grad).abs().sum().item() / max(sd_f[n].grad.abs().sum().item(), 1e-9)
+        if e > worst:
+            worst, worst_name = e, n
+    print(f"dulcet_L3: loss diff {errs['loss']:.1e} dx {errs['dx']:.1e} dctx {errs['dctx']:.1e}; worst parameter gradient L1 error {worst:.1e} ({worst_name})")
+    assert errs["loss"] < 2e-4 and errs["dx"] < 2e-4 and errs["dctx"] < 2e-4 and worst < 2e-4
