@@ -653,7 +653,7 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             if (f16) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 5>(p, s);
             else if (split) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 3>(p, s);
             else launch_cfg<128, 64, 4, 1, EPI_LINEAR>(p, s);
-        } else if (L.N_pad % 128 == 0 || L.N_pad > 320 || (split && L.n_alloc >= round_up(L.N_pad, 128))) {
+        } else if (L.N_pad % 128 == 0 || L.N_pad > 320 || ((split || f16) && L.n_alloc >= round_up(L.N_pad, 128))) {
             // (with the split-bf16 loop two co-resident 128x128 workgroups beat the one-wave-per-SIMD 128x320 tile even at N = 320)
             // Default for the split-fp16 loop: 128x128 tile on EIGHT waves of 32x64 (64 accumulator registers per lane instead of
             // 128 -> 118 VGPRs -> 4 waves per SIMD instead of 2): +4 ... +19 % over four waves of 64x64 on every layer shape, and

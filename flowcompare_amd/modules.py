@@ -315,12 +315,15 @@ class Flow(nn.Module):
         as produced by inner_loop (constant over N) or None.  `eps`: optional list of explicit noise
         tensors (shapes: noise_shapes) making the stochastic forward reproducible; drawn with
         torch.randn when omitted, like the reference's rsample()."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and x.requires_grad:
-            raise RuntimeError("flowcompare_amd: backward through the HIP flow engine is not implemented (SURVEY.md §8f N1)")
         B, N = x.shape[0], x.shape[1]
         if eps is None:
             eps = [torch.randn(s, device=x.device, dtype=torch.float32) for s in self.noise_shapes(B, N)]
         self.last_eps = eps
+        if torch.is_grad_enabled() and (self.training or x.requires_grad or (context is not None and context.requires_grad)):
+            # training (train.py:108-112): the differentiable path over the HIP training primitives (train_flow.py); the fused
+            # inference engine below has no backward
+            from . import train_flow
+            return train_flow.flow_log_prob(self, x, context, extra_context, eps)
         return self._engine().log_prob(x, context, extra_context, eps)
 
     def sample(self, num_samples, n_points, context=None, sample_distrib=None, extra_context=None, eps=None):

@@ -18,6 +18,7 @@ the global-context pre-conditioner, ExponentialCoupling and the alternative perm
 import math
 
 import torch
+import torch.utils.checkpoint
 
 from . import modules as M
 from . import train_ops as T
@@ -55,9 +56,10 @@ def _lu_weight(perm):
     return L @ U, torch.log(diag).sum()
 
 
-def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None):
+def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, checkpoint=True):
     """log p(x | context) [B, N] with autograd through HIP kernels.  Arguments as Flow.log_prob (modules.py); `eps` pins the
-    augmenter noise.  Call inside train_ops.step_guard() to run the split-fp16 loops with the range flag."""
+    augmenter noise; `checkpoint` recomputes each layer's forward during backward (only layer inputs stay resident).
+    Call inside train_ops.step_guard() to run the split-fp16 loops with the range flag."""
     cfg = flow._config
     act = act or cfg["coupling_block_nonlinearity"]
     B, N, Din = x.shape
@@ -74,7 +76,6 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None):
     extra_panel = None if X == 0 else T.to_panel(extra_context.reshape(rows, X).to(torch.float32))
     x_panel = T.to_panel(x.reshape(rows, Din))
     logp = torch.zeros(x_panel.shape[0], dtype=torch.float32, device=x.device)
-    const = torch.zeros((), dtype=torch.float32, device=x.device)
     eps = list(eps) if eps is not None else None
     transforms = list(flow.transforms)
 
@@ -103,56 +104,99 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None):
     x1 = T.to_panel(latent[:, :d1])
     x2 = T.to_panel(latent[:, d1:D])
 
-    # ---- layers
+    # ---- layers: each one (pre-conditioner + coupling + ActNorm + permuter) is a function of (x1, x2, logp, context) so that it can be
+    #      wrapped in torch.utils.checkpoint: only the layer inputs stay resident and the layer's forward is recomputed during
+    #      backward, which is also what the reference does for the pre-conditioner (models/cif_block.py:17-19).  Without it the
+    #      saved activations of C2 (115 layers x ~4 GB at 16 x 4096 points) would not fit even in 288 GB.
+    def make_layer(blk, an, perm):
+        pc, cp = blk.pre_conditioner, blk.transform
+
+        def layer(x1, x2, logp, ctx_panel, extra_panel):
+            k, v = _kv(pc.attn, ctx_panel, E, ctx_rows)
+            h = T.mlp_panels(pc.pre_attention_mlp, [x1], [d1], rows, act)
+            c, c_w = _attention_block(pc.attn, h, pc.pre_attention_mlp.out_layer.out_features, k, v, rows, B, N, Mctx)
+            segs, widths = [x1], [d1]
+            if X:
+                segs.append(extra_panel); widths.append(X)
+            segs.append(c); widths.append(c_w)
+            p = T.mlp_panels(cp.nn, segs, widths, rows, act)
+            if isinstance(cp, M.RationalQuadraticSplineCoupling):
+                x2, ldj = T.rq_spline(x2, p, rows, d2, cp.num_bins)
+                logp = logp + ldj
+            else:
+                raw, t = p[:, :d2], p[:, d2:2 * d2]
+                s = torch.exp(raw) if cp.scale_fn_type == "exp" else (2 * torch.sigmoid(raw) - 1) * (1 - 1e-8) + 1
+                logp = logp + torch.log(s).sum(-1)
+                x2 = T.to_panel(x2[:, :d2] * s + t)
+            # ActNorm and the permuter between layers, applied as ONE Linear on (x1 | x2)
+            W, b = None, None
+            if an is not None:
+                g = torch.exp(-an.log_scale.reshape(-1))
+                W, b = torch.diag(g), -an.shift.reshape(-1) * g
+                logp = logp - an.log_scale.sum()
+            if perm is not None:
+                Wlu, logdet = _lu_weight(perm)
+                W, b = (Wlu, None) if W is None else (Wlu @ W, Wlu @ b)
+                logp = logp + logdet
+            if W is not None:
+                z1 = T.linear_act([x1, x2], [d1, d2], W[:d1], None if b is None else b[:d1], rows)
+                z2 = T.linear_act([x1, x2], [d1, d2], W[d1:], None if b is None else b[d1:], rows)
+                x1, x2 = z1, z2
+            return x1, x2, logp
+        return layer
+
     i = 1
     while i < len(transforms):
         blk = transforms[i]
         if not isinstance(blk, M.PreConditionApplier) or not isinstance(blk.pre_conditioner, M.CouplingPreconditionerAttn):
             raise NotImplementedError(f"training path: transform {type(blk).__name__} is not built yet (CIFblock / global context)")
-        pc, cp = blk.pre_conditioner, blk.transform
-        k, v = _kv(pc.attn, ctx_panel, E, ctx_rows)
-        h = T.mlp_panels(pc.pre_attention_mlp, [x1], [d1], rows, act)
-        c, c_w = _attention_block(pc.attn, h, pc.pre_attention_mlp.out_layer.out_features, k, v, rows, B, N, Mctx)
-        segs, widths = [x1], [d1]
-        if X:
-            segs.append(extra_panel); widths.append(X)
-        segs.append(c); widths.append(c_w)
-        p = T.mlp_panels(cp.nn, segs, widths, rows, act)
-        if isinstance(cp, M.RationalQuadraticSplineCoupling):
-            x2, ldj = T.rq_spline(x2, p, rows, d2, cp.num_bins)
-            logp = logp + ldj
-        elif isinstance(cp, M.AffineCoupling):
-            raw, t = p[:, :d2], p[:, d2:2 * d2]
-            s = torch.exp(raw) if cp.scale_fn_type == "exp" else (2 * torch.sigmoid(raw) - 1) * (1 - 1e-8) + 1
-            y2 = x2[:, :d2] * s + t
-            logp = logp + torch.log(s).sum(-1)
-            x2 = T.to_panel(y2)
-        else:
-            raise NotImplementedError(f"training path: coupling {type(cp).__name__}")
+        if not isinstance(blk.transform, (M.RationalQuadraticSplineCoupling, M.AffineCoupling)):
+            raise NotImplementedError(f"training path: coupling {type(blk.transform).__name__}")
         i += 1
-        # ---- ActNorm and the permuter between layers, applied as ONE Linear on (x1 | x2)
-        W, b = None, None
+        an = perm = None
         if i < len(transforms) and isinstance(transforms[i], M.ActNormBijectionCloud):
             an = transforms[i]
             if float(an.initialized.item()) == 0.0:
                 raise NotImplementedError("training path: data-dependent ActNorm initialisation (act_norm.py:27-35) is not built yet; "
-                                          "run one forward through the reference-compatible init or load a checkpoint")
-            g = torch.exp(-an.log_scale.reshape(-1))
-            W, b = torch.diag(g), -an.shift.reshape(-1) * g
-            const = const - an.log_scale.sum()
+                                          "load a checkpoint or set the statistics first")
             i += 1
         if i < len(transforms) and isinstance(transforms[i], M.LinearLU):
-            Wlu, logdet = _lu_weight(transforms[i])
-            W, b = (Wlu, None) if W is None else (Wlu @ W, Wlu @ b)
-            const = const + logdet
+            perm = transforms[i]
             i += 1
         elif i < len(transforms) and not isinstance(transforms[i], M.PreConditionApplier):
             raise NotImplementedError(f"training path: permuter {type(transforms[i]).__name__} is not built yet")
-        if W is not None:
-            z1 = T.linear_act([x1, x2], [d1, d2], W[:d1], None if b is None else b[:d1], rows)
-            z2 = T.linear_act([x1, x2], [d1, d2], W[d1:], None if b is None else b[d1:], rows)
-            x1, x2 = z1, z2
+        fn = make_layer(blk, an, perm)
+        if checkpoint and torch.is_grad_enabled():
+            x1, x2, logp = torch.utils.checkpoint.checkpoint(fn, x1, x2, logp, ctx_panel, extra_panel, use_reentrant=False)
+        else:
+            x1, x2, logp = fn(x1, x2, logp, ctx_panel, extra_panel)
 
     # ---- base density (models/distributions.py:192-195)
-    logp = logp + (-0.5 * (x1 * x1).sum(-1) - 0.5 * (x2 * x2).sum(-1)) - 0.5 * D * LOG_2PI + const
+    logp = logp + (-0.5 * (x1 * x1).sum(-1) - 0.5 * (x2 * x2).sum(-1)) - 0.5 * D * LOG_2PI
     return logp[:rows].reshape(B, N)
+
+
+def training_step(batch, models_dict, config, optimizer=None, eps=None, grad_clip=None):
+    """One optimisation step as train.py:108-120 runs it: inner_loop -> loss.backward() -> clip_grad_norm_ -> optimizer.step().
+    The flow must be in train() mode (or the inputs require grad) so that Flow.log_prob takes the differentiable HIP path; the
+    context embedder runs its inference kernels (eval-mode BatchNorm) and receives no gradient yet (its backward is the next row).
+    Range guard: the step runs on the split-fp16 loops first and is repeated on the fp32-input loops if any operand left the fp16
+    range.  Returns (loss, log_prob, bpd, grad_norm)."""
+    from .model_initialization import inner_loop
+    params = [p for p in models_dict["parameters"] if p.requires_grad]
+    device = batch[1].device
+    for fp16 in (True, False):
+        for p in params:
+            p.grad = None
+        with T.step_guard(fp16=fp16, device=device) as guard:
+            loss, log_prob, bpd = inner_loop(batch, models_dict, config, eps=eps)
+            loss.backward()
+            if not guard.overflowed():
+                break
+    clip = config.get("grad_clip_val") if grad_clip is None else grad_clip
+    with_grad = [p for p in params if p.grad is not None]
+    norm = torch.nn.utils.clip_grad_norm_(with_grad, max_norm=clip if clip else float("inf"))
+    if optimizer is not None:
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+    return loss.detach(), log_prob.detach(), bpd, norm
