@@ -151,7 +151,7 @@ constexpr int WG_LD = 128 + 4;             // LDS pitch in floats
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ du, int ldu, int du_cols, const float* __restrict__ x, int ldx,
                                                     int x_cols, int rows_valid, int chunk_rows, int tiles_k, float* __restrict__ part,
-                                                    int part_rows, int part_ld) {
+                                                    int part_rows, int part_ld, float* __restrict__ colpart, int colpart_ld) {
     __shared__ float sA[WG_PS * WG_LD];
     __shared__ float sB[WG_PS * WG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -179,6 +179,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ du
             rb[h] = (ok && b_ok) ? *reinterpret_cast<const float4*>(x + (size_t)p * ldx + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // bias gradient for free: the du slab is in LDS anyway, so the workgroups of the first k tile also sum its columns
+    // (thread t < 128 owns column n0 + t; rows beyond the chunk were staged as zeros)
+    const bool do_cols = colpart != nullptr && tk == 0 && tid < 128;
+    float csum = 0.f;
     if (p_begin < p_end) gload(p_begin);
     for (int p0 = p_begin; p0 < p_end; p0 += WG_PS) {
         __syncthreads();                                  // the previous slab's reads are done
@@ -189,6 +193,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ du
         }
         __syncthreads();
         if (p0 + WG_PS < p_end) gload(p0 + WG_PS);
+        if (do_cols) {
+            float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < WG_PS; r += 2) { t0 += sA[r * WG_LD + tid]; t1 += sA[(r + 1) * WG_LD + tid]; }
+            csum += t0 + t1;
+        }
 #pragma unroll
         for (int kk = 0; kk < WG_PS / 2; ++kk) {
             const int row = 2 * kk + (lane >> 5);
@@ -204,6 +214,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ du
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
+    if (do_cols && n0 + tid < du_cols) colpart[(size_t)blockIdx.y * colpart_ld + n0 + tid] = csum;
     float* out = part + (size_t)blockIdx.y * part_rows * part_ld;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -289,12 +300,12 @@ static WgradPlan wgrad_plan(const TrainLinearLayout& L, int rows) {
         tiles_max = std::max(tiles_max, (w.n128 / 128) * (round_up(L.seg_pad[i], 128) / 128));
     }
     // enough workgroups for 256 CUs x 2, slabs of at least 512 rows
-    w.S = std::max(1, std::min(std::max(1, 1024 / tiles_max), std::max(1, rows / 512)));
+    w.S = std::max(1, std::min(std::max(1, 512 / tiles_max), std::max(1, rows / 512)));
     w.chunk = round_up((rows + w.S - 1) / w.S, WG_PS);
     w.part_floats = (size_t)w.S * w.n128 * w.k128max;
     w.S2 = colsum_chunks(rows);
     w.chunk2 = (rows + w.S2 - 1) / w.S2;
-    w.colsum_floats = (size_t)w.S2 * L.N_pad;
+    w.colsum_floats = (size_t)std::max(w.S, w.S2) * round_up(L.N_pad, 128);
     w.bytes = round_up_sz(w.part_floats * 4, 256) + round_up_sz(w.colsum_floats * 4, 256);
     return w;
 }
@@ -411,7 +422,7 @@ int fc_train_linear_wgrad_f32(int32_t N, const int32_t* seg_widths, int32_t nseg
             {
                 ProfScope ps("fc::wgrad_kernel", 2.0 * rows * (double)L.N * L.seg[i], 0.0, s);
                 hipLaunchKernelGGL(wgrad_kernel, dim3(tiles_n * tiles_k, w.S), dim3(256), 0, s, du, ldu, L.N_pad, x[i], ldx[i], L.seg_pad[i], rows,
-                                   w.chunk, tiles_k, part, w.n128, k128);
+                                   w.chunk, tiles_k, part, w.n128, k128, (db && i == 0) ? cpart : nullptr, w.n128);
                 FC_HIP(hipGetLastError());
             }
             const size_t total = (size_t)L.N * L.seg[i];
@@ -422,7 +433,11 @@ int fc_train_linear_wgrad_f32(int32_t N, const int32_t* seg_widths, int32_t nseg
             k_off += L.seg[i];
         }
     }
-    if (db) {
+    if (db && dW) {
+        // column partials came out of the first segment's wgrad launch: [S][n128]
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((L.N + 255) / 256), dim3(256), 0, s, cpart, w.S, w.n128, db, L.N, accumulate);
+        FC_HIP(hipGetLastError());
+    } else if (db) {
         ProfScope ps("fc::colsum_kernel", 0.0, (double)rows * L.N * 4.0, s);
         hipLaunchKernelGGL(colsum_kernel, dim3((L.N + 255) / 256, w.S2), dim3(256), 0, s, du, ldu, L.N, rows, w.chunk2, cpart, L.N_pad);
         FC_HIP(hipGetLastError());

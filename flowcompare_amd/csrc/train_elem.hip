@@ -209,6 +209,102 @@ __global__ __launch_bounds__(256) void layernorm_train_bwd_kernel(const float* _
     }
 }
 
+
+// ---------------------------------------------------------------- the three per-element closures of the flow, one workgroup per point
+// affine coupling (models/affine_coupling.py:23-46): st = [raw scale d2 | shift d2];  y2 = x2 s + t,  ldj = sum log s
+__device__ __forceinline__ float affine_scale(float raw, int scale_fn, float& ds) {
+    if (scale_fn == FC_SCALE_EXP) { const float s = expf(raw); ds = s; return s; }
+    const float sg = 1.0f / (1.0f + expf(-raw));
+    ds = 2.0f * sg * (1.0f - sg) * (float)(1.0 - 1e-8);
+    return (2.0f * sg - 1.0f) * (float)(1.0 - 1e-8) + 1.0f;
+}
+__global__ __launch_bounds__(256) void affine_train_fwd_kernel(const float* __restrict__ x2, int ldx, const float* __restrict__ st, int ldst,
+                                                               float* __restrict__ y2, int ldy, float* __restrict__ ldj, int d2, int d2_pad, int scale_fn) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    float part = 0.f;
+    for (int j = threadIdx.x; j < d2_pad; j += 256) {
+        float y = 0.f;
+        if (j < d2) {
+            float ds;
+            const float s = affine_scale(st[row * ldst + j], scale_fn, ds);
+            y = x2[row * ldx + j] * s + st[row * ldst + d2 + j];
+            part += logf(s);
+        }
+        y2[row * ldy + j] = y;
+    }
+    const float tot = block_sum_256(part, red);
+    if (threadIdx.x == 0) ldj[row] = tot;
+}
+__global__ __launch_bounds__(256) void affine_train_bwd_kernel(const float* __restrict__ x2, int ldx, const float* __restrict__ st, int ldst,
+                                                               const float* __restrict__ dy2, int lddy, const float* __restrict__ dldj,
+                                                               float* __restrict__ dx2, int lddx, float* __restrict__ dst, int lddst, int d2,
+                                                               int d2_pad, int nst_pad, int scale_fn) {
+    const size_t row = blockIdx.x;
+    const float gl = dldj[row];
+    for (int j = threadIdx.x; j < d2_pad; j += 256) {
+        float gx = 0.f;
+        if (j < d2) {
+            float ds;
+            const float s = affine_scale(st[row * ldst + j], scale_fn, ds);
+            const float gy = dy2[row * lddy + j];
+            gx = gy * s;
+            dst[row * lddst + j] = (gy * x2[row * ldx + j] + gl / s) * ds;
+            dst[row * lddst + d2 + j] = gy;
+        }
+        dx2[row * lddx + j] = gx;
+    }
+    for (int c = 2 * d2 + threadIdx.x; c < nst_pad; c += 256) dst[row * lddst + c] = 0.f;
+}
+
+// augmenter draw (models/augmenter.py:49-63, distributions.py:128-153): p = [mean nz | log std nz];  z = mean + eps exp(log std),
+// ldj = -log N(z; mean, std) summed = sum (eps^2 / 2 + log std + log(2 pi) / 2)
+__global__ __launch_bounds__(256) void gauss_train_fwd_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ eps, float* __restrict__ z,
+                                                              int ldz, float* __restrict__ ldj, int nz, int nz_pad) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    float part = 0.f;
+    for (int j = threadIdx.x; j < nz_pad; j += 256) {
+        float v = 0.f;
+        if (j < nz) {
+            const float e = eps[row * nz + j], ls = p[row * ldp + nz + j];
+            v = p[row * ldp + j] + e * expf(ls);
+            part += 0.5f * e * e + ls + 0.91893853320467274178f;
+        }
+        z[row * ldz + j] = v;
+    }
+    const float tot = block_sum_256(part, red);
+    if (threadIdx.x == 0) ldj[row] = tot;
+}
+__global__ __launch_bounds__(256) void gauss_train_bwd_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ eps,
+                                                              const float* __restrict__ dz, int lddz, const float* __restrict__ dldj,
+                                                              float* __restrict__ dp, int lddp, int nz, int np_pad) {
+    const size_t row = blockIdx.x;
+    const float gl = dldj[row];
+    for (int j = threadIdx.x; j < nz; j += 256) {
+        const float g = dz[row * lddz + j];
+        dp[row * lddp + j] = g;
+        dp[row * lddp + nz + j] = g * eps[row * nz + j] * expf(p[row * ldp + nz + j]) + gl;
+    }
+    for (int c = 2 * nz + threadIdx.x; c < np_pad; c += 256) dp[row * lddp + c] = 0.f;
+}
+
+// base density (models/distributions.py:192-195): out[row] = sum_c (-x^2 / 2 - log(2 pi) / 2) over `width` columns
+__global__ __launch_bounds__(256) void base_train_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int width) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    float part = 0.f;
+    for (int j = threadIdx.x; j < width; j += 256) { const float v = x[row * ldx + j]; part -= 0.5f * v * v; }
+    const float tot = block_sum_256(part, red);
+    if (threadIdx.x == 0) out[row] = tot - 0.91893853320467274178f * width;
+}
+__global__ __launch_bounds__(256) void base_train_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g, float* __restrict__ dx,
+                                                             int lddx, int width, int width_pad) {
+    const size_t row = blockIdx.x;
+    const float gr = g[row];
+    for (int j = threadIdx.x; j < width_pad; j += 256) dx[row * lddx + j] = j < width ? -x[row * ldx + j] * gr : 0.f;
+}
+
 template <int K>
 static void spline_fwd_k(const float* x2, int ldx, const float* params, int ldp, float* y2, int ldy, float* ldj, int rows, int d2, hipStream_t s) {
     ProfScope ps("fc::spline_train_fwd_kernel", 0.0, (double)rows * d2 * (3 * K + 3) * 4.0, s);
@@ -291,6 +387,73 @@ int fc_train_layernorm_bwd_f32(const float* x, int32_t ldx, const float* gamma, 
     ProfScope ps("fc::layernorm_train_bwd_kernel", 0.0, (double)rows * width * 16.0, s);
     hipLaunchKernelGGL(layernorm_train_bwd_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, s, x, ldx, gamma, dy, lddy, stats, dx, lddx, dy_xhat, ldt,
                        rows, rows_pad, width, round_up(width, 32));
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_affine_fwd_f32(const float* x2, int32_t ldx, const float* st, int32_t ldst, float* y2, int32_t ldy, float* ldj, int32_t rows, int32_t d2,
+                            int32_t scale_fn, void* stream) {
+    FC_API_BEGIN
+    if (!x2 || !st || !y2 || !ldj || rows < 1 || d2 < 1 || ldx < d2 || ldst < 2 * d2 || ldy < round_up(d2, 32)) throw Error(FC_ERR_INVALID, "fc_train_affine_fwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::affine_train_fwd_kernel", 0.0, (double)rows * d2 * 16.0, s);
+    hipLaunchKernelGGL(affine_train_fwd_kernel, dim3(rows), dim3(256), 0, s, x2, ldx, st, ldst, y2, ldy, ldj, d2, round_up(d2, 32), scale_fn);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_affine_bwd_f32(const float* x2, int32_t ldx, const float* st, int32_t ldst, const float* dy2, int32_t lddy, const float* dldj, float* dx2,
+                            int32_t lddx, float* dst, int32_t lddst, int32_t rows, int32_t d2, int32_t scale_fn, void* stream) {
+    FC_API_BEGIN
+    if (!x2 || !st || !dy2 || !dldj || !dx2 || !dst || rows < 1 || d2 < 1 || ldx < d2 || ldst < 2 * d2 || lddy < d2 || lddx < round_up(d2, 32) ||
+        lddst < round_up(2 * d2, 32))
+        throw Error(FC_ERR_INVALID, "fc_train_affine_bwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::affine_train_bwd_kernel", 0.0, (double)rows * d2 * 28.0, s);
+    hipLaunchKernelGGL(affine_train_bwd_kernel, dim3(rows), dim3(256), 0, s, x2, ldx, st, ldst, dy2, lddy, dldj, dx2, lddx, dst, lddst, d2, round_up(d2, 32),
+                       round_up(2 * d2, 32), scale_fn);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_gauss_fwd_f32(const float* p, int32_t ldp, const float* eps, float* z, int32_t ldz, float* ldj, int32_t rows, int32_t nz, void* stream) {
+    FC_API_BEGIN
+    if (!p || !eps || !z || !ldj || rows < 1 || nz < 1 || ldp < 2 * nz || ldz < round_up(nz, 32)) throw Error(FC_ERR_INVALID, "fc_train_gauss_fwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::gauss_train_fwd_kernel", 0.0, (double)rows * nz * 16.0, s);
+    hipLaunchKernelGGL(gauss_train_fwd_kernel, dim3(rows), dim3(256), 0, s, p, ldp, eps, z, ldz, ldj, nz, round_up(nz, 32));
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_gauss_bwd_f32(const float* p, int32_t ldp, const float* eps, const float* dz, int32_t lddz, const float* dldj, float* dp, int32_t lddp,
+                           int32_t rows, int32_t nz, void* stream) {
+    FC_API_BEGIN
+    if (!p || !eps || !dz || !dldj || !dp || rows < 1 || nz < 1 || ldp < 2 * nz || lddz < nz || lddp < round_up(2 * nz, 32))
+        throw Error(FC_ERR_INVALID, "fc_train_gauss_bwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::gauss_train_bwd_kernel", 0.0, (double)rows * nz * 24.0, s);
+    hipLaunchKernelGGL(gauss_train_bwd_kernel, dim3(rows), dim3(256), 0, s, p, ldp, eps, dz, lddz, dldj, dp, lddp, nz, round_up(2 * nz, 32));
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_base_fwd_f32(const float* x, int32_t ldx, float* out, int32_t rows, int32_t width, void* stream) {
+    FC_API_BEGIN
+    if (!x || !out || rows < 1 || width < 1 || ldx < width) throw Error(FC_ERR_INVALID, "fc_train_base_fwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::base_train_fwd_kernel", 0.0, (double)rows * width * 4.0, s);
+    hipLaunchKernelGGL(base_train_fwd_kernel, dim3(rows), dim3(256), 0, s, x, ldx, out, width);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_base_bwd_f32(const float* x, int32_t ldx, const float* g, float* dx, int32_t lddx, int32_t rows, int32_t width, void* stream) {
+    FC_API_BEGIN
+    if (!x || !g || !dx || rows < 1 || width < 1 || ldx < width || lddx < round_up(width, 32)) throw Error(FC_ERR_INVALID, "fc_train_base_bwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::base_train_bwd_kernel", 0.0, (double)rows * width * 8.0, s);
+    hipLaunchKernelGGL(base_train_bwd_kernel, dim3(rows), dim3(256), 0, s, x, ldx, g, dx, lddx, width, round_up(width, 32));
     FC_HIP(hipGetLastError());
     FC_API_END
 }

@@ -8,8 +8,8 @@ What runs where
     one Linear (act_norm.py:37-43, permuters.py:164-169) -- is a HIP kernel, forward and backward;
   * parameter-space algebra (building L, U and W = L U diag(exp(-log_scale)) from the LinearLU / ActNorm parameters, 300 x 300) is
     ordinary differentiable torch on the parameters: torch.autograd carries dW back to lower_entries / upper_entries / log_scale / shift;
-  * the three cheap per-element closures (affine scale-and-shift, the augmenter's reparameterised draw, the base density) are torch
-    elementwise expressions on the HIP tensors in this first cut (DESIGN.md §10 lists them as the next kernels).
+  * the per-element closures (affine scale-and-shift, the augmenter's reparameterised draw, the base density) are HIP kernels too;
+    what torch does on activations is data movement only (pad, slice, cat of panels) and the running sum of the per-point log-dets.
 
 Covered: AugmentAttentionPreconditioner or IdentityTransform, PreConditionApplier(CouplingPreconditionerAttn) with
 RationalQuadraticSplineCoupling or AffineCoupling, ActNormBijectionCloud (initialised), LinearLU, extra context.  Not yet: CIFblock,
@@ -91,12 +91,10 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
             segs.append(extra_panel); widths.append(X)
         segs.append(a); widths.append(a_w)
         p = T.mlp_panels(t0.augment.noise_dist.net, segs, widths, rows, act)
-        mean, log_std = p[:, :nz], p[:, nz:2 * nz]
         e = eps.pop(0) if eps else torch.randn(B, N, nz, device=x.device)
-        e = torch.nn.functional.pad(e.reshape(rows, nz).to(torch.float32), (0, 0, 0, x_panel.shape[0] - rows))
-        z2 = mean + e * torch.exp(log_std)
-        logp = logp + (0.5 * e * e + log_std + 0.5 * LOG_2PI).sum(-1)            # -log N(z2; mean, std)
-        latent = torch.cat((x_panel[:, :Din], z2), -1)
+        z2, ldj = T.gauss_draw(p, e.reshape(rows, nz), rows, nz)                   # z2 = mean + eps std ; ldj = -log N(z2; mean, std)
+        logp = logp + ldj
+        latent = torch.cat((x_panel[:, :Din], z2[:, :nz]), -1)
     elif isinstance(t0, M.IdentityTransform):
         latent = x_panel[:, :Din]
     else:
@@ -124,10 +122,8 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
                 x2, ldj = T.rq_spline(x2, p, rows, d2, cp.num_bins)
                 logp = logp + ldj
             else:
-                raw, t = p[:, :d2], p[:, d2:2 * d2]
-                s = torch.exp(raw) if cp.scale_fn_type == "exp" else (2 * torch.sigmoid(raw) - 1) * (1 - 1e-8) + 1
-                logp = logp + torch.log(s).sum(-1)
-                x2 = T.to_panel(x2[:, :d2] * s + t)
+                x2, ldj = T.affine(x2, p, rows, d2, cp.scale_fn_type)
+                logp = logp + ldj
             # ActNorm and the permuter between layers, applied as ONE Linear on (x1 | x2)
             W, b = None, None
             if an is not None:
@@ -172,7 +168,7 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
             x1, x2, logp = fn(x1, x2, logp, ctx_panel, extra_panel)
 
     # ---- base density (models/distributions.py:192-195)
-    logp = logp + (-0.5 * (x1 * x1).sum(-1) - 0.5 * (x2 * x2).sum(-1)) - 0.5 * D * LOG_2PI
+    logp = logp + T.base_density(x1, rows, d1) + T.base_density(x2, rows, d2)
     return logp[:rows].reshape(B, N)
 
 

@@ -329,3 +329,106 @@ class LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x, gamma, beta, rows, eps=1e-5):
     return LayerNormFn.apply(x, gamma, beta, rows, eps)
+
+
+SCALE_IDS = {"exp": 0, "sigmoid": 1}
+
+
+class AffineFn(torch.autograd.Function):
+    """Affine coupling element (models/affine_coupling.py:23-46): x2 panel, st panel [raw scale d2 | shift d2] -> (y2 panel, ldj)."""
+
+    @staticmethod
+    def forward(ctx, x2, st, rows, d2, scale_fn):
+        L = engine.lib()
+        _check_panel(x2, d2)
+        _check_panel(st, 2 * d2)
+        y2 = torch.zeros(x2.shape[0], _round_up(d2, 32), dtype=torch.float32, device=x2.device)
+        ldj = torch.zeros(x2.shape[0], dtype=torch.float32, device=x2.device)
+        with torch.cuda.device(x2.device):
+            engine._check(L.fc_train_affine_fwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(st), st.shape[1], engine._ptr(y2), y2.shape[1],
+                                                    engine._ptr(ldj), rows, d2, scale_fn, engine._stream()))
+        ctx.save_for_backward(x2, st)
+        ctx.meta = (rows, d2, scale_fn)
+        return y2, ldj
+
+    @staticmethod
+    def backward(ctx, dy2, dldj):
+        L = engine.lib()
+        x2, st = ctx.saved_tensors
+        rows, d2, scale_fn = ctx.meta
+        dy2, dldj = dy2.contiguous(), dldj.contiguous()
+        dx2, dst = torch.zeros_like(x2), torch.zeros_like(st)
+        with torch.cuda.device(x2.device):
+            engine._check(L.fc_train_affine_bwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(st), st.shape[1], engine._ptr(dy2), dy2.shape[1],
+                                                    engine._ptr(dldj), engine._ptr(dx2), dx2.shape[1], engine._ptr(dst), dst.shape[1], rows, d2,
+                                                    scale_fn, engine._stream()))
+        return dx2, dst, None, None, None
+
+
+def affine(x2, st, rows, d2, scale_fn_type):
+    return AffineFn.apply(x2, st, rows, d2, SCALE_IDS[scale_fn_type])
+
+
+class GaussDrawFn(torch.autograd.Function):
+    """Reparameterised draw of the augmenter (models/augmenter.py:49-63): p panel [mean nz | log std nz], eps [rows, nz] ->
+    (z panel, ldj = -log N(z; mean, std) summed over the nz dims)."""
+
+    @staticmethod
+    def forward(ctx, p, eps, rows, nz):
+        L = engine.lib()
+        _check_panel(p, 2 * nz)
+        eps = eps.to(torch.float32).contiguous()
+        z = torch.zeros(p.shape[0], _round_up(nz, 32), dtype=torch.float32, device=p.device)
+        ldj = torch.zeros(p.shape[0], dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            engine._check(L.fc_train_gauss_fwd_f32(engine._ptr(p), p.shape[1], engine._ptr(eps), engine._ptr(z), z.shape[1], engine._ptr(ldj), rows, nz,
+                                                   engine._stream()))
+        ctx.save_for_backward(p, eps)
+        ctx.meta = (rows, nz)
+        return z, ldj
+
+    @staticmethod
+    def backward(ctx, dz, dldj):
+        L = engine.lib()
+        p, eps = ctx.saved_tensors
+        rows, nz = ctx.meta
+        dz, dldj = dz.contiguous(), dldj.contiguous()
+        dp = torch.zeros_like(p)
+        with torch.cuda.device(p.device):
+            engine._check(L.fc_train_gauss_bwd_f32(engine._ptr(p), p.shape[1], engine._ptr(eps), engine._ptr(dz), dz.shape[1], engine._ptr(dldj),
+                                                   engine._ptr(dp), dp.shape[1], rows, nz, engine._stream()))
+        return dp, None, None, None
+
+
+def gauss_draw(p, eps, rows, nz):
+    return GaussDrawFn.apply(p, eps, rows, nz)
+
+
+class BaseDensityFn(torch.autograd.Function):
+    """Standard-normal log-density of a panel's `width` true columns per row (models/distributions.py:192-195)."""
+
+    @staticmethod
+    def forward(ctx, x, rows, width):
+        L = engine.lib()
+        _check_panel(x, width)
+        out = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            engine._check(L.fc_train_base_fwd_f32(engine._ptr(x), x.shape[1], engine._ptr(out), rows, width, engine._stream()))
+        ctx.save_for_backward(x)
+        ctx.meta = (rows, width)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = engine.lib()
+        (x,) = ctx.saved_tensors
+        rows, width = ctx.meta
+        g = g.contiguous()
+        dx = torch.zeros_like(x)
+        with torch.cuda.device(x.device):
+            engine._check(L.fc_train_base_bwd_f32(engine._ptr(x), x.shape[1], engine._ptr(g), engine._ptr(dx), dx.shape[1], rows, width, engine._stream()))
+        return dx, None, None
+
+
+def base_density(x, rows, width):
+    return BaseDensityFn.apply(x, rows, width)

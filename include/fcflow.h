@@ -246,6 +246,20 @@ int fc_train_layernorm_fwd_f32(const float* x, int32_t ldx, const float* gamma, 
                                int32_t rows, int32_t width, float eps, void* stream);
 int fc_train_layernorm_bwd_f32(const float* x, int32_t ldx, const float* gamma, const float* dy, int32_t lddy, const float* stats, float* dx,
                                int32_t lddx, float* dy_xhat, int32_t ldt, int32_t rows_pad, int32_t rows, int32_t width, void* stream);
+/* The per-element closures of the flow, forward and backward, one workgroup per point (pad columns written as zeros):
+ *   affine  models/affine_coupling.py:23-46   st = [raw scale d2 | shift d2]: y2 = x2 s + t, ldj[row] = sum log s (scale_fn: enum fc_scale_fn)
+ *   gauss   models/augmenter.py:49-63 + distributions.py:128-153   p = [mean nz | log std nz], eps [rows, nz] dense:
+ *           z = mean + eps exp(log std), ldj[row] = -sum log N(z; mean, std)
+ *   base    models/distributions.py:192-195   out[row] = sum over `width` columns of -x^2/2 - log(2 pi)/2 */
+int fc_train_affine_fwd_f32(const float* x2, int32_t ldx, const float* st, int32_t ldst, float* y2, int32_t ldy, float* ldj, int32_t rows, int32_t d2,
+                            int32_t scale_fn, void* stream);
+int fc_train_affine_bwd_f32(const float* x2, int32_t ldx, const float* st, int32_t ldst, const float* dy2, int32_t lddy, const float* dldj, float* dx2,
+                            int32_t lddx, float* dst, int32_t lddst, int32_t rows, int32_t d2, int32_t scale_fn, void* stream);
+int fc_train_gauss_fwd_f32(const float* p, int32_t ldp, const float* eps, float* z, int32_t ldz, float* ldj, int32_t rows, int32_t nz, void* stream);
+int fc_train_gauss_bwd_f32(const float* p, int32_t ldp, const float* eps, const float* dz, int32_t lddz, const float* dldj, float* dp, int32_t lddp,
+                           int32_t rows, int32_t nz, void* stream);
+int fc_train_base_fwd_f32(const float* x, int32_t ldx, float* out, int32_t rows, int32_t width, void* stream);
+int fc_train_base_bwd_f32(const float* x, int32_t ldx, const float* g, float* dx, int32_t lddx, int32_t rows, int32_t width, void* stream);
 size_t fc_train_colsum_ws_bytes(int32_t cols, int32_t rows);
 int fc_train_colsum_f32(const float* a, int32_t lda, int32_t cols, int32_t rows, float* out, int32_t accumulate, void* ws, size_t ws_bytes,
                         void* stream);

@@ -308,3 +308,49 @@ def test_flow_backward_with_extra_context_matches_oracle_autograd():
             worst, worst_name = e, n
     print(f"dulcet_L3: loss diff {errs['loss']:.1e} dx {errs['dx']:.1e} dctx {errs['dctx']:.1e}; worst parameter gradient L1 error {worst:.1e} ({worst_name})")
     assert errs["loss"] < 2e-4 and errs["dx"] < 2e-4 and errs["dctx"] < 2e-4 and worst < 2e-4
+
+
+def test_deep_stack_gradients_are_as_close_to_fp64_as_eager_fp32():
+    """Module-initialised weights make a deep stack ill-conditioned (the forward already differs by O(1e-3) nats between fp32 and fp64
+    at 8 layers, tests/test_gpu_fullsize.py): the whole-gradient distance of the HIP training path from fp64 autograd through the
+    pinned oracle must be no worse than that of the same oracle in fp32 (eager PyTorch, the arithmetic the reference trains in)."""
+    cfg = fa.named_config("c2_dgcnn_attn_spline", n_flow_layers=8, sample_size=192)
+    torch.manual_seed(21)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    for m in md["flow"].modules():
+        if hasattr(m, "initialized"):
+            m.initialized.fill_(1.0)
+    g = torch.Generator().manual_seed(22)
+    B, N, Mc = 2, 192, 200
+    x = torch.rand(B, N, 6, generator=g)
+    ctx = torch.randn(B, Mc, 64, generator=g) * 0.5
+    eps = [torch.randn(B, N, 294, generator=g)]
+    md["flow"].zero_grad()
+    with T.step_guard(device=DEV) as guard:
+        lp = TF.flow_log_prob(md["flow"], x.to(DEV), ctx.to(DEV), None, [e.to(DEV) for e in eps])
+        (-lp.mean()).backward()
+        assert not guard.overflowed()
+    c = dict(cfg)
+
+    def oracle(dtype):
+        sd = {k: v.detach().cpu().to(dtype) if v.is_floating_point() else v.cpu() for k, v in md["flow"].state_dict().items()}
+        for v in sd.values():
+            if v.is_floating_point():
+                v.requires_grad_(True)
+        lo = O.flow_log_prob(c, sd, x.to(dtype), ctx.to(dtype), None, [e.to(dtype) for e in eps])
+        (-lo.mean()).backward()
+        return lo.detach().double(), sd
+    lp64, sd64 = oracle(torch.float64)
+    lp32, sd32 = oracle(torch.float32)
+    num_h = num_32 = den = 0.0
+    for n, p in md["flow"].named_parameters():
+        if sd64[n].grad is None:
+            continue
+        g64 = sd64[n].grad
+        num_h += float(((p.grad.double().cpu() - g64) ** 2).sum())
+        num_32 += float(((sd32[n].grad.double() - g64) ** 2).sum())
+        den += float((g64 ** 2).sum())
+    e_h, e_32 = (num_h / den) ** 0.5, (num_32 / den) ** 0.5
+    d_h, d_32 = (lp.detach().cpu().double() - lp64).abs().max().item(), (lp32 - lp64).abs().max().item()
+    print(f"8 layers at real widths: |g - g64| / |g64|: HIP {e_h:.2e}, fp32 oracle {e_32:.2e}; log-prob max diff: HIP {d_h:.2e}, fp32 oracle {d_32:.2e}")
+    assert e_h < 3.0 * e_32 + 1e-5
