@@ -228,6 +228,132 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ du
             }
 }
 
+// ---------------------------------------------------------------- the same product on the split-fp16 loop (default inside a guard scope)
+// Operands go global -> registers (fp32) -> fp16 limbs (hi, lo' = (x - hi) 2048, gemm.hip) -> LDS row-major [p][hi 128 | lo' 128];
+// the MFMA operands (8 consecutive-in-p halfs of one column per lane) come out of LDS through ds_read_b64_tr_b16, the transposing
+// read the forward attention uses for P.V: a 16-lane group reads a [4 rows][16 columns] block and lane i receives column i.  Each
+// lane's k-group therefore holds rows {4h .. 4h+3, 8+4h .. 8+4h+3} of the 16-row step -- the same permutation for both operands, so
+// the contraction is unchanged.  3 MFMAs (v_mfma_f32_32x32x16_f16) per block and step: hi.hi into `main`, hi.lo' + lo'.hi into `cross`.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+
+constexpr int W16_ROWS = 32;               // rows per staged slab (two MFMA k-steps)
+constexpr int W16_PITCH = 512 + 32;        // bytes per LDS row: [hi 128 halfs | lo' 128 halfs] + pad
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad16_kernel(const float* __restrict__ du, int ldu, int du_cols, const float* __restrict__ x, int ldx,
+                                                      int x_cols, int rows_valid, int chunk_rows, int tiles_k, float* __restrict__ part,
+                                                      int part_rows, int part_ld, float* __restrict__ colpart, int colpart_ld, int* __restrict__ ovf) {
+    __shared__ __attribute__((aligned(16))) char sA[2 * W16_ROWS * W16_PITCH];      // two stages each
+    __shared__ __attribute__((aligned(16))) char sB[2 * W16_ROWS * W16_PITCH];
+    constexpr int STAGE = W16_ROWS * W16_PITCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lh = lane >> 5;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int p_begin = blockIdx.y * chunk_rows, p_end = min(rows_valid, p_begin + chunk_rows);
+    const int lr = tid >> 5, lc = (tid & 31) * 4;
+    const bool a_ok = n0 + lc < du_cols, b_ok = k0 + lc < x_cols;
+    const bool do_cols = colpart != nullptr && tk == 0;
+    f32x16 om[2][2], oc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { om[i][j][r] = 0.f; oc[i][j][r] = 0.f; }
+    float4 ra[4], rb[4];
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float amax = 0.f;
+    auto gload = [&](int p0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int p = p0 + lr + 8 * h;
+            const bool ok = p < p_end;
+            ra[h] = (ok && a_ok) ? *reinterpret_cast<const float4*>(du + (size_t)p * ldu + n0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[h] = (ok && b_ok) ? *reinterpret_cast<const float4*>(x + (size_t)p * ldx + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto split_store = [&](char* base, const float4& v) {
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        f16x4 hi, lo;
+        hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+        lo[0] = (_Float16)((v.x - (float)hi[0]) * 2048.0f); lo[1] = (_Float16)((v.y - (float)hi[1]) * 2048.0f);
+        lo[2] = (_Float16)((v.z - (float)hi[2]) * 2048.0f); lo[3] = (_Float16)((v.w - (float)hi[3]) * 2048.0f);
+        *reinterpret_cast<f16x4*>(base) = hi;
+        *reinterpret_cast<f16x4*>(base + 256) = lo;
+    };
+    // transposed-read address of this lane inside a [4 rows][16 columns] block (attention.hip): lane 4q+c of a 16-lane group supplies
+    // row q, columns 4c .. 4c+3; the group's columns are 16 ((lane >> 4) & 1) .. +15 of the 32-column block, its rows start at 4 lh
+    const int tr_off = (4 * lh + ((lane & 15) >> 2)) * W16_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    auto lstore = [&](int st) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (do_cols) { csum.x += ra[h].x; csum.y += ra[h].y; csum.z += ra[h].z; csum.w += ra[h].w; }
+            split_store(sA + st * STAGE + (lr + 8 * h) * W16_PITCH + lc * 2, ra[h]);
+            split_store(sB + st * STAGE + (lr + 8 * h) * W16_PITCH + lc * 2, rb[h]);
+        }
+    };
+    // software pipeline: slab t is multiplied out of LDS stage t & 1 while slab t + 1 (already in registers) is converted and stored
+    // into the other stage and slab t + 2 is fetched from HBM; one barrier per slab
+    if (p_begin < p_end) { gload(p_begin); lstore(0); }
+    if (p_begin + W16_ROWS < p_end) gload(p_begin + W16_ROWS);
+    int st = 0;
+    for (int p0 = p_begin; p0 < p_end; p0 += W16_ROWS, st ^= 1) {
+        __syncthreads();                                  // stage st is complete; every wave has finished reading stage st ^ 1
+#pragma unroll
+        for (int ks = 0; ks < W16_ROWS / 16; ++ks) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#define FC_TR(PTR_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(PTR_))
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* pa = sA + st * STAGE + (16 * ks) * W16_PITCH + (wn * 64 + i * 32) * 2 + tr_off;
+                const char* pb = sB + st * STAGE + (16 * ks) * W16_PITCH + (wk * 64 + i * 32) * 2 + tr_off;
+                ah[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pa), FC_TR(pa + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
+                al[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pa + 256), FC_TR(pa + 256 + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
+                bh[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pb), FC_TR(pb + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
+                bl[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pb + 256), FC_TR(pb + 256 + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#undef FC_TR
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    om[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], om[i][j], 0, 0, 0);
+                    oc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], oc[i][j], 0, 0, 0);
+                    oc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], oc[i][j], 0, 0, 0);
+                }
+            if (ks == 0 && p0 + W16_ROWS < p_end) lstore(st ^ 1);        // the next slab's limbs, under this slab's MFMAs
+        }
+        if (p0 + 2 * W16_ROWS < p_end) gload(p0 + 2 * W16_ROWS);
+    }
+    if (amax >= 65504.0f || amax != amax) atomicOr(ovf, 1);
+    if (do_cols) {
+        // the 8 thread rows (tid >> 5) of the staging grid each summed their own rows of the chunk: add them in a fixed order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(sA);
+        *reinterpret_cast<float4*>(red + lr * 128 + lc) = csum;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < du_cols) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += red[r * 128 + tid];
+            colpart[(size_t)blockIdx.y * colpart_ld + n0 + tid] = t;
+        }
+    }
+    float* out = part + (size_t)blockIdx.y * part_rows * part_ld;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int k = k0 + wk * 64 + j * 32 + (lane & 31);
+                out[(size_t)n * part_ld + k] = om[i][j][r] + oc[i][j][r] * (1.0f / 2048.0f);
+            }
+}
+
 // dW[n][k_off + k] (=|+=) sum_s part[s][n][k]   for n < N, k < k_true: fixed summation order
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int part_rows, int part_ld, float* __restrict__ dW, int N, int K,
                                     int k_off, int k_true, int accumulate) {
@@ -287,6 +413,7 @@ __global__ void colsum_reduce_kernel(const float* __restrict__ part, int S, int 
 }
 
 // ---------------------------------------------------------------- host side
+int g_train_wgrad16 = 1;      // tuning knob (fc_debug_set 11): weight gradients on the split-fp16 loop inside a guard scope
 static int grid_for(size_t n, int block) { return (int)std::min<size_t>((n + block - 1) / block, 256 * 16); }
 
 struct WgradPlan { int S, chunk, n128, k128max, S2, chunk2; size_t part_floats, colsum_floats, bytes; };
@@ -301,7 +428,7 @@ static WgradPlan wgrad_plan(const TrainLinearLayout& L, int rows) {
     }
     // enough workgroups for 256 CUs x 2, slabs of at least 512 rows
     w.S = std::max(1, std::min(std::max(1, 512 / tiles_max), std::max(1, rows / 512)));
-    w.chunk = round_up((rows + w.S - 1) / w.S, WG_PS);
+    w.chunk = round_up((rows + w.S - 1) / w.S, W16_ROWS);
     w.part_floats = (size_t)w.S * w.n128 * w.k128max;
     w.S2 = colsum_chunks(rows);
     w.chunk2 = (rows + w.S2 - 1) / w.S2;
@@ -404,7 +531,8 @@ size_t fc_train_linear_wgrad_ws_bytes(int32_t N, const int32_t* seg_widths, int3
 }
 
 int fc_train_linear_wgrad_f32(int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu, const float* const* x,
-                              const int32_t* ldx, int32_t rows, float* dW, float* db, int32_t accumulate, void* ws, size_t ws_bytes, void* stream) {
+                              const int32_t* ldx, int32_t rows, float* dW, float* db, int32_t accumulate, void* ws, size_t ws_bytes, int32_t* ovf,
+                              void* stream) {
     FC_API_BEGIN
     const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
     if (!x || !ldx || rows < 1 || (!dW && !db)) throw Error(FC_ERR_INVALID, "fc_train_linear_wgrad_f32: bad argument");
@@ -419,7 +547,12 @@ int fc_train_linear_wgrad_f32(int32_t N, const int32_t* seg_widths, int32_t nseg
         for (int i = 0; i < L.nseg; ++i) {
             check_panel(x[i], ldx[i], L.seg_pad[i], "x");
             const int k128 = round_up(L.seg_pad[i], 128), tiles_k = k128 / 128, tiles_n = w.n128 / 128;
-            {
+            if (ovf && g_train_wgrad16) {
+                ProfScope ps("fc::wgrad16_kernel", 2.0 * rows * (double)L.N * L.seg[i], 0.0, s);
+                hipLaunchKernelGGL(wgrad16_kernel, dim3(tiles_n * tiles_k, w.S), dim3(256), 0, s, du, ldu, L.N_pad, x[i], ldx[i], L.seg_pad[i], rows,
+                                   w.chunk, tiles_k, part, w.n128, k128, (db && i == 0) ? cpart : nullptr, w.n128, (int*)ovf);
+                FC_HIP(hipGetLastError());
+            } else {
                 ProfScope ps("fc::wgrad_kernel", 2.0 * rows * (double)L.N * L.seg[i], 0.0, s);
                 hipLaunchKernelGGL(wgrad_kernel, dim3(tiles_n * tiles_k, w.S), dim3(256), 0, s, du, ldu, L.N_pad, x[i], ldx[i], L.seg_pad[i], rows,
                                    w.chunk, tiles_k, part, w.n128, k128, (db && i == 0) ? cpart : nullptr, w.n128);

@@ -153,7 +153,7 @@ class LinearActFn(torch.autograd.Function):
                 db = torch.empty(N, dtype=torch.float32, device=dev) if (has_bias and need[1]) else None
                 ldx = _segs([x.shape[1] for x in xs])
                 engine._check(L.fc_train_linear_wgrad_f32(N, segs, len(widths), engine._ptr(du), N_pad, _ptr_array(xs), ldx, rows,
-                                                          engine._ptr(dW), engine._ptr(db), 0, engine._ptr(ws), ctypes.c_size_t(nb), s))
+                                                          engine._ptr(dW), engine._ptr(db), 0, engine._ptr(ws), ctypes.c_size_t(nb), _flag_ptr(), s))
             dxs = [None] * len(xs)
             if any(need[6:]):
                 K_pad = sum(_round_up(w, 32) for w in widths)

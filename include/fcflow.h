@@ -216,7 +216,7 @@ size_t fc_train_linear_wgrad_ws_bytes(int32_t N, const int32_t* seg_widths, int3
  * fixed summation order (bit-reproducible).  ws: 256-byte aligned scratch of fc_train_linear_wgrad_ws_bytes. */
 int fc_train_linear_wgrad_f32(int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu, const float* const* x,
                               const int32_t* ldx, int32_t rows, float* dW, float* db, int32_t accumulate, void* ws, size_t ws_bytes,
-                              void* stream);
+                              int32_t* ovf, void* stream);
 /* y = act(u) and du = dy * act'(u) on dense [rows_pad, ld] panels (enum fc_act; GELU is the exact erf form);
  * rows >= `rows` of du are written as zeros. */
 int fc_train_act_fwd_f32(const float* u, float* y, int32_t rows_pad, int32_t ld, int32_t act, void* stream);
