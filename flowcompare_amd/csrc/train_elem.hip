@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void affine_train_bwd_kernel(const float* __re
 // augmenter draw (models/augmenter.py:49-63, distributions.py:128-153): p = [mean nz | log std nz];  z = mean + eps exp(log std),
 // ldj = -log N(z; mean, std) summed = sum (eps^2 / 2 + log std + log(2 pi) / 2)
 __global__ __launch_bounds__(256) void gauss_train_fwd_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ eps, float* __restrict__ z,
-                                                              int ldz, float* __restrict__ ldj, int nz, int nz_pad) {
+                                                              int ldz, float* __restrict__ ldj, int nz, int nz_pad, float clamp) {
     __shared__ float red[4];
     const size_t row = blockIdx.x;
     float part = 0.f;
@@ -268,8 +268,10 @@ __global__ __launch_bounds__(256) void gauss_train_fwd_kernel(const float* __res
         float v = 0.f;
         if (j < nz) {
             const float e = eps[row * nz + j], ls = p[row * ldp + nz + j];
-            v = p[row * ldp + j] + e * expf(ls);
-            part += 0.5f * e * e + ls + 0.91893853320467274178f;
+            float sc = expf(ls), lsc = ls;
+            if (clamp > 0.f && sc > clamp) { sc = clamp; lsc = logf(clamp); }          // distributions.py:134-137 (clamp_max on the std)
+            v = p[row * ldp + j] + e * sc;
+            part += 0.5f * e * e + lsc + 0.91893853320467274178f;
         }
         z[row * ldz + j] = v;
     }
@@ -278,13 +280,51 @@ __global__ __launch_bounds__(256) void gauss_train_fwd_kernel(const float* __res
 }
 __global__ __launch_bounds__(256) void gauss_train_bwd_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ eps,
                                                               const float* __restrict__ dz, int lddz, const float* __restrict__ dldj,
-                                                              float* __restrict__ dp, int lddp, int nz, int np_pad) {
+                                                              float* __restrict__ dp, int lddp, int nz, int np_pad, float clamp) {
     const size_t row = blockIdx.x;
     const float gl = dldj[row];
     for (int j = threadIdx.x; j < nz; j += 256) {
         const float g = dz[row * lddz + j];
+        const float sc = expf(p[row * ldp + nz + j]);
         dp[row * lddp + j] = g;
-        dp[row * lddp + nz + j] = g * eps[row * nz + j] * expf(p[row * ldp + nz + j]) + gl;
+        dp[row * lddp + nz + j] = (clamp > 0.f && sc > clamp) ? 0.f : g * eps[row * nz + j] * sc + gl;
+    }
+    for (int c = 2 * nz + threadIdx.x; c < np_pad; c += 256) dp[row * lddp + c] = 0.f;
+}
+
+// Slice (models/slice.py:31-44 + distributions.py:140-142): out[row] = sum_j log N(v_j; mean_j, std_j), p = [mean nz | log std nz]
+__global__ __launch_bounds__(256) void normlp_train_fwd_kernel(const float* __restrict__ v, int ldv, const float* __restrict__ p, int ldp,
+                                                               float* __restrict__ out, int nz, float clamp) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    float part = 0.f;
+    for (int j = threadIdx.x; j < nz; j += 256) {
+        const float ls = p[row * ldp + nz + j];
+        float sc = expf(ls), lsc = ls;
+        if (clamp > 0.f && sc > clamp) { sc = clamp; lsc = logf(clamp); }
+        const float d = (v[row * ldv + j] - p[row * ldp + j]) / sc;
+        part += -0.5f * d * d - lsc - 0.91893853320467274178f;
+    }
+    const float tot = block_sum_256(part, red);
+    if (threadIdx.x == 0) out[row] = tot;
+}
+__global__ __launch_bounds__(256) void normlp_train_bwd_kernel(const float* __restrict__ v, int ldv, const float* __restrict__ p, int ldp,
+                                                               const float* __restrict__ g, float* __restrict__ dv, int lddv, float* __restrict__ dp,
+                                                               int lddp, int nz, int nz_pad, int np_pad, float clamp) {
+    const size_t row = blockIdx.x;
+    const float gr = g[row];
+    for (int j = threadIdx.x; j < nz_pad; j += 256) {
+        float gv = 0.f;
+        if (j < nz) {
+            const float sc0 = expf(p[row * ldp + nz + j]);
+            const bool cl = clamp > 0.f && sc0 > clamp;
+            const float sc = cl ? clamp : sc0;
+            const float d = (v[row * ldv + j] - p[row * ldp + j]) / sc;
+            gv = -gr * d / sc;
+            dp[row * lddp + j] = -gv;
+            dp[row * lddp + nz + j] = cl ? 0.f : gr * (d * d - 1.0f);
+        }
+        dv[row * lddv + j] = gv;
     }
     for (int c = 2 * nz + threadIdx.x; c < np_pad; c += 256) dp[row * lddp + c] = 0.f;
 }
@@ -416,24 +456,48 @@ int fc_train_affine_bwd_f32(const float* x2, int32_t ldx, const float* st, int32
     FC_API_END
 }
 
-int fc_train_gauss_fwd_f32(const float* p, int32_t ldp, const float* eps, float* z, int32_t ldz, float* ldj, int32_t rows, int32_t nz, void* stream) {
+int fc_train_gauss_fwd_f32(const float* p, int32_t ldp, const float* eps, float* z, int32_t ldz, float* ldj, int32_t rows, int32_t nz, float clamp,
+                           void* stream) {
     FC_API_BEGIN
     if (!p || !eps || !z || !ldj || rows < 1 || nz < 1 || ldp < 2 * nz || ldz < round_up(nz, 32)) throw Error(FC_ERR_INVALID, "fc_train_gauss_fwd_f32: bad argument");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("fc::gauss_train_fwd_kernel", 0.0, (double)rows * nz * 16.0, s);
-    hipLaunchKernelGGL(gauss_train_fwd_kernel, dim3(rows), dim3(256), 0, s, p, ldp, eps, z, ldz, ldj, nz, round_up(nz, 32));
+    hipLaunchKernelGGL(gauss_train_fwd_kernel, dim3(rows), dim3(256), 0, s, p, ldp, eps, z, ldz, ldj, nz, round_up(nz, 32), clamp);
     FC_HIP(hipGetLastError());
     FC_API_END
 }
 
 int fc_train_gauss_bwd_f32(const float* p, int32_t ldp, const float* eps, const float* dz, int32_t lddz, const float* dldj, float* dp, int32_t lddp,
-                           int32_t rows, int32_t nz, void* stream) {
+                           int32_t rows, int32_t nz, float clamp, void* stream) {
     FC_API_BEGIN
     if (!p || !eps || !dz || !dldj || !dp || rows < 1 || nz < 1 || ldp < 2 * nz || lddz < nz || lddp < round_up(2 * nz, 32))
         throw Error(FC_ERR_INVALID, "fc_train_gauss_bwd_f32: bad argument");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("fc::gauss_train_bwd_kernel", 0.0, (double)rows * nz * 24.0, s);
-    hipLaunchKernelGGL(gauss_train_bwd_kernel, dim3(rows), dim3(256), 0, s, p, ldp, eps, dz, lddz, dldj, dp, lddp, nz, round_up(2 * nz, 32));
+    hipLaunchKernelGGL(gauss_train_bwd_kernel, dim3(rows), dim3(256), 0, s, p, ldp, eps, dz, lddz, dldj, dp, lddp, nz, round_up(2 * nz, 32), clamp);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_normlp_fwd_f32(const float* v, int32_t ldv, const float* p, int32_t ldp, float* out, int32_t rows, int32_t nz, float clamp, void* stream) {
+    FC_API_BEGIN
+    if (!v || !p || !out || rows < 1 || nz < 1 || ldv < nz || ldp < 2 * nz) throw Error(FC_ERR_INVALID, "fc_train_normlp_fwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::normlp_train_fwd_kernel", 0.0, (double)rows * nz * 12.0, s);
+    hipLaunchKernelGGL(normlp_train_fwd_kernel, dim3(rows), dim3(256), 0, s, v, ldv, p, ldp, out, nz, clamp);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_normlp_bwd_f32(const float* v, int32_t ldv, const float* p, int32_t ldp, const float* g, float* dv, int32_t lddv, float* dp, int32_t lddp,
+                            int32_t rows, int32_t nz, float clamp, void* stream) {
+    FC_API_BEGIN
+    if (!v || !p || !g || !dv || !dp || rows < 1 || nz < 1 || ldv < nz || ldp < 2 * nz || lddv < round_up(nz, 32) || lddp < round_up(2 * nz, 32))
+        throw Error(FC_ERR_INVALID, "fc_train_normlp_bwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::normlp_train_bwd_kernel", 0.0, (double)rows * nz * 24.0, s);
+    hipLaunchKernelGGL(normlp_train_bwd_kernel, dim3(rows), dim3(256), 0, s, v, ldv, p, ldp, g, dv, lddv, dp, lddp, nz, round_up(nz, 32), round_up(2 * nz, 32),
+                       clamp);
     FC_HIP(hipGetLastError());
     FC_API_END
 }

@@ -11,9 +11,10 @@ What runs where
   * the per-element closures (affine scale-and-shift, the augmenter's reparameterised draw, the base density) are HIP kernels too;
     what torch does on activations is data movement only (pad, slice, cat of panels) and the running sum of the per-point log-dets.
 
-Covered: AugmentAttentionPreconditioner or IdentityTransform, PreConditionApplier(CouplingPreconditionerAttn) with
-RationalQuadraticSplineCoupling or AffineCoupling, ActNormBijectionCloud (initialised), LinearLU, extra context.  Not yet: CIFblock,
-the global-context pre-conditioner, ExponentialCoupling and the alternative permuters (they raise NotImplementedError).
+Covered: AugmentAttentionPreconditioner or IdentityTransform; PreConditionApplier with the attention or the global-context
+pre-conditioner; CIFblock (augment / affine_cif / ActNorm / Slice around the coupling); RationalQuadraticSplineCoupling or
+AffineCoupling; ActNormBijectionCloud (initialised); LinearLU; extra context.  Not yet: ExponentialCoupling and the alternative
+permuters (they raise NotImplementedError).
 """
 import math
 
@@ -67,8 +68,6 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
     d1 = D // 2
     d2 = D - d1
     rows = B * N
-    if cfg.get("global"):
-        raise NotImplementedError("training path: the global-context pre-conditioner is not built yet")
     Mctx, E = context.shape[1], context.shape[2]
     ctx_rows = B * Mctx
     ctx_panel = T.to_panel(context.reshape(ctx_rows, E))
@@ -106,24 +105,60 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
     #      wrapped in torch.utils.checkpoint: only the layer inputs stay resident and the layer's forward is recomputed during
     #      backward, which is also what the reference does for the pre-conditioner (models/cif_block.py:17-19).  Without it the
     #      saved activations of C2 (115 layers x ~4 GB at 16 x 4096 points) would not fit even in 288 GB.
-    def make_layer(blk, an, perm):
-        pc, cp = blk.pre_conditioner, blk.transform
-
-        def layer(x1, x2, logp, ctx_panel, extra_panel):
+    def conditioned_coupling(pc, cp, x1, x2, logp, ctx_panel, extra_panel, mlp_act):
+        """PreConditionApplier (models/transform.py:47-52): conditioning vector from x1 (attention over the context, or the
+        per-point global embedding itself), then the coupling on x2."""
+        if isinstance(pc, M.CouplingPreconditionerGlobal):
+            if ctx_rows != rows:
+                raise RuntimeError("global context must be per target point: context [B, N, E]")
+            c, c_w = ctx_panel, E
+        else:
             k, v = _kv(pc.attn, ctx_panel, E, ctx_rows)
-            h = T.mlp_panels(pc.pre_attention_mlp, [x1], [d1], rows, act)
+            h = T.mlp_panels(pc.pre_attention_mlp, [x1], [d1], rows, mlp_act)
             c, c_w = _attention_block(pc.attn, h, pc.pre_attention_mlp.out_layer.out_features, k, v, rows, B, N, Mctx)
-            segs, widths = [x1], [d1]
-            if X:
-                segs.append(extra_panel); widths.append(X)
-            segs.append(c); widths.append(c_w)
-            p = T.mlp_panels(cp.nn, segs, widths, rows, act)
-            if isinstance(cp, M.RationalQuadraticSplineCoupling):
-                x2, ldj = T.rq_spline(x2, p, rows, d2, cp.num_bins)
+        segs, widths = [x1], [d1]
+        if X:
+            segs.append(extra_panel); widths.append(X)
+        segs.append(c); widths.append(c_w)
+        p = T.mlp_panels(cp.nn, segs, widths, rows, act)
+        if isinstance(cp, M.RationalQuadraticSplineCoupling):
+            x2, ldj = T.rq_spline(x2, p, rows, d2, cp.num_bins)
+        else:
+            x2, ldj = T.affine(x2, p, rows, d2, cp.scale_fn_type)
+        return x2, logp + ldj
+
+    def make_layer(blk, an, perm):
+        cif = isinstance(blk, M.CIFblock)
+
+        def layer(x1, x2, logp, ctx_panel, extra_panel, e):
+            if cif:
+                # CIFblock.forward (models/cif_block.py:71-100): augment D -> Dc from x, Reverse, affine coupling of the x part
+                # conditioned on the noise part, ActNorm(Dc), Reverse, Slice back to D (same ConditionalNormal), then the coupling
+                Dc = cfg["cif_latent_dim"]
+                nz = Dc - D
+                net = blk.augmenter.noise_dist.net
+                clamp = float(blk.augmenter.noise_dist.clamp or 0.0)
+                p = T.mlp_panels(net, [x1, x2], [d1, d2], rows, "GELU")
+                z2, ldj = T.gauss_draw(p, e, rows, nz, clamp)
                 logp = logp + ldj
+                a = T.to_panel(torch.flip(z2[:, :nz], [-1]))                                   # first nz dims of rev(cat(x, z2))
+                b = T.to_panel(torch.flip(torch.cat((x1[:, :d1], x2[:, :d2]), -1), [-1]))      # last D dims: rev(x)
+                st = T.mlp_panels(blk.affine_cif.nn, [a], [nz], rows, "GELU")
+                b, ldj = T.affine(b, st, rows, D, "sigmoid")
+                logp = logp + ldj
+                # ActNorm(Dc) followed by Reverse, as one Linear on (a | b) whose weight is a flipped diagonal (parameter space)
+                g = torch.exp(-blk.act_norm.log_scale.reshape(-1))
+                W = torch.diag(g).flip(0)
+                bias = (-blk.act_norm.shift.reshape(-1) * g).flip(0)
+                logp = logp - blk.act_norm.log_scale.sum()
+                x1 = T.linear_act([a, b], [nz, D], W[:d1], bias[:d1], rows)
+                x2 = T.linear_act([a, b], [nz, D], W[d1:D], bias[d1:D], rows)
+                xs = T.linear_act([a, b], [nz, D], W[D:], bias[D:], rows)
+                p2 = T.mlp_panels(net, [x1, x2], [d1, d2], rows, "GELU")
+                logp = logp + T.normal_log_prob(xs, p2, rows, nz, clamp)
+                x2, logp = conditioned_coupling(blk.flow.pre_conditioner, blk.flow.transform, x1, x2, logp, ctx_panel, None, "GELU")
             else:
-                x2, ldj = T.affine(x2, p, rows, d2, cp.scale_fn_type)
-                logp = logp + ldj
+                x2, logp = conditioned_coupling(blk.pre_conditioner, blk.transform, x1, x2, logp, ctx_panel, extra_panel, act)
             # ActNorm and the permuter between layers, applied as ONE Linear on (x1 | x2)
             W, b = None, None
             if an is not None:
@@ -144,28 +179,40 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
     i = 1
     while i < len(transforms):
         blk = transforms[i]
-        if not isinstance(blk, M.PreConditionApplier) or not isinstance(blk.pre_conditioner, M.CouplingPreconditionerAttn):
-            raise NotImplementedError(f"training path: transform {type(blk).__name__} is not built yet (CIFblock / global context)")
-        if not isinstance(blk.transform, (M.RationalQuadraticSplineCoupling, M.AffineCoupling)):
-            raise NotImplementedError(f"training path: coupling {type(blk.transform).__name__}")
+        if isinstance(blk, M.CIFblock):
+            inner = blk.flow
+            if X:
+                raise Exception("Not implemented extra context with cif")
+        elif isinstance(blk, M.PreConditionApplier):
+            inner = blk
+        else:
+            raise NotImplementedError(f"training path: transform {type(blk).__name__}")
+        if not isinstance(inner.transform, (M.RationalQuadraticSplineCoupling, M.AffineCoupling)):
+            raise NotImplementedError(f"training path: coupling {type(inner.transform).__name__} is not built yet")
         i += 1
         an = perm = None
         if i < len(transforms) and isinstance(transforms[i], M.ActNormBijectionCloud):
             an = transforms[i]
-            if float(an.initialized.item()) == 0.0:
-                raise NotImplementedError("training path: data-dependent ActNorm initialisation (act_norm.py:27-35) is not built yet; "
-                                          "load a checkpoint or set the statistics first")
             i += 1
         if i < len(transforms) and isinstance(transforms[i], M.LinearLU):
             perm = transforms[i]
             i += 1
-        elif i < len(transforms) and not isinstance(transforms[i], M.PreConditionApplier):
+        elif i < len(transforms) and not isinstance(transforms[i], (M.PreConditionApplier, M.CIFblock)):
             raise NotImplementedError(f"training path: permuter {type(transforms[i]).__name__} is not built yet")
+        for a_n in ([an] if an is not None else []) + ([blk.act_norm] if isinstance(blk, M.CIFblock) else []):
+            if float(a_n.initialized.item()) == 0.0:
+                raise NotImplementedError("training path: data-dependent ActNorm initialisation (act_norm.py:27-35) is not built yet; "
+                                          "load a checkpoint or set the statistics first")
+        e = None
+        if isinstance(blk, M.CIFblock):
+            nzc = cfg["cif_latent_dim"] - D
+            e = eps.pop(0) if eps else torch.randn(B, N, nzc, device=x.device)
+            e = e.reshape(rows, nzc)
         fn = make_layer(blk, an, perm)
         if checkpoint and torch.is_grad_enabled():
-            x1, x2, logp = torch.utils.checkpoint.checkpoint(fn, x1, x2, logp, ctx_panel, extra_panel, use_reentrant=False)
+            x1, x2, logp = torch.utils.checkpoint.checkpoint(fn, x1, x2, logp, ctx_panel, extra_panel, e, use_reentrant=False)
         else:
-            x1, x2, logp = fn(x1, x2, logp, ctx_panel, extra_panel)
+            x1, x2, logp = fn(x1, x2, logp, ctx_panel, extra_panel, e)
 
     # ---- base density (models/distributions.py:192-195)
     logp = logp + T.base_density(x1, rows, d1) + T.base_density(x2, rows, d2)

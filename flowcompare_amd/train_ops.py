@@ -371,10 +371,10 @@ def affine(x2, st, rows, d2, scale_fn_type):
 
 class GaussDrawFn(torch.autograd.Function):
     """Reparameterised draw of the augmenter (models/augmenter.py:49-63): p panel [mean nz | log std nz], eps [rows, nz] ->
-    (z panel, ldj = -log N(z; mean, std) summed over the nz dims)."""
+    (z panel, ldj = -log N(z; mean, std) summed over the nz dims); std = min(exp(log std), clamp) when clamp > 0."""
 
     @staticmethod
-    def forward(ctx, p, eps, rows, nz):
+    def forward(ctx, p, eps, rows, nz, clamp):
         L = engine.lib()
         _check_panel(p, 2 * nz)
         eps = eps.to(torch.float32).contiguous()
@@ -382,26 +382,59 @@ class GaussDrawFn(torch.autograd.Function):
         ldj = torch.zeros(p.shape[0], dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
             engine._check(L.fc_train_gauss_fwd_f32(engine._ptr(p), p.shape[1], engine._ptr(eps), engine._ptr(z), z.shape[1], engine._ptr(ldj), rows, nz,
-                                                   engine._stream()))
+                                                   ctypes.c_float(clamp), engine._stream()))
         ctx.save_for_backward(p, eps)
-        ctx.meta = (rows, nz)
+        ctx.meta = (rows, nz, clamp)
         return z, ldj
 
     @staticmethod
     def backward(ctx, dz, dldj):
         L = engine.lib()
         p, eps = ctx.saved_tensors
-        rows, nz = ctx.meta
+        rows, nz, clamp = ctx.meta
         dz, dldj = dz.contiguous(), dldj.contiguous()
         dp = torch.zeros_like(p)
         with torch.cuda.device(p.device):
             engine._check(L.fc_train_gauss_bwd_f32(engine._ptr(p), p.shape[1], engine._ptr(eps), engine._ptr(dz), dz.shape[1], engine._ptr(dldj),
-                                                   engine._ptr(dp), dp.shape[1], rows, nz, engine._stream()))
-        return dp, None, None, None
+                                                   engine._ptr(dp), dp.shape[1], rows, nz, ctypes.c_float(clamp), engine._stream()))
+        return dp, None, None, None, None
 
 
-def gauss_draw(p, eps, rows, nz):
-    return GaussDrawFn.apply(p, eps, rows, nz)
+def gauss_draw(p, eps, rows, nz, clamp=0.0):
+    return GaussDrawFn.apply(p, eps, rows, nz, float(clamp or 0.0))
+
+
+class NormalLogProbFn(torch.autograd.Function):
+    """sum_j log N(v_j; mean_j, std_j) per row (Slice.forward, models/slice.py:31-44); p panel [mean nz | log std nz]."""
+
+    @staticmethod
+    def forward(ctx, v, p, rows, nz, clamp):
+        L = engine.lib()
+        _check_panel(v, nz)
+        _check_panel(p, 2 * nz)
+        out = torch.zeros(v.shape[0], dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            engine._check(L.fc_train_normlp_fwd_f32(engine._ptr(v), v.shape[1], engine._ptr(p), p.shape[1], engine._ptr(out), rows, nz,
+                                                    ctypes.c_float(clamp), engine._stream()))
+        ctx.save_for_backward(v, p)
+        ctx.meta = (rows, nz, clamp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = engine.lib()
+        v, p = ctx.saved_tensors
+        rows, nz, clamp = ctx.meta
+        g = g.contiguous()
+        dv, dp = torch.zeros_like(v), torch.zeros_like(p)
+        with torch.cuda.device(v.device):
+            engine._check(L.fc_train_normlp_bwd_f32(engine._ptr(v), v.shape[1], engine._ptr(p), p.shape[1], engine._ptr(g), engine._ptr(dv), dv.shape[1],
+                                                    engine._ptr(dp), dp.shape[1], rows, nz, ctypes.c_float(clamp), engine._stream()))
+        return dv, dp, None, None, None
+
+
+def normal_log_prob(v, p, rows, nz, clamp=0.0):
+    return NormalLogProbFn.apply(v, p, rows, nz, float(clamp or 0.0))
 
 
 class BaseDensityFn(torch.autograd.Function):

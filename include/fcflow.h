@@ -249,15 +249,20 @@ int fc_train_layernorm_bwd_f32(const float* x, int32_t ldx, const float* gamma, 
 /* The per-element closures of the flow, forward and backward, one workgroup per point (pad columns written as zeros):
  *   affine  models/affine_coupling.py:23-46   st = [raw scale d2 | shift d2]: y2 = x2 s + t, ldj[row] = sum log s (scale_fn: enum fc_scale_fn)
  *   gauss   models/augmenter.py:49-63 + distributions.py:128-153   p = [mean nz | log std nz], eps [rows, nz] dense:
- *           z = mean + eps exp(log std), ldj[row] = -sum log N(z; mean, std)
+ *           z = mean + eps std, ldj[row] = -sum log N(z; mean, std); std = min(exp(log std), clamp) when clamp > 0 (CIF blocks)
+ *   normlp  models/slice.py:31-44   out[row] = sum_j log N(v_j; mean_j, std_j), same parameter panel and clamp
  *   base    models/distributions.py:192-195   out[row] = sum over `width` columns of -x^2/2 - log(2 pi)/2 */
 int fc_train_affine_fwd_f32(const float* x2, int32_t ldx, const float* st, int32_t ldst, float* y2, int32_t ldy, float* ldj, int32_t rows, int32_t d2,
                             int32_t scale_fn, void* stream);
 int fc_train_affine_bwd_f32(const float* x2, int32_t ldx, const float* st, int32_t ldst, const float* dy2, int32_t lddy, const float* dldj, float* dx2,
                             int32_t lddx, float* dst, int32_t lddst, int32_t rows, int32_t d2, int32_t scale_fn, void* stream);
-int fc_train_gauss_fwd_f32(const float* p, int32_t ldp, const float* eps, float* z, int32_t ldz, float* ldj, int32_t rows, int32_t nz, void* stream);
+int fc_train_gauss_fwd_f32(const float* p, int32_t ldp, const float* eps, float* z, int32_t ldz, float* ldj, int32_t rows, int32_t nz, float clamp,
+                           void* stream);
 int fc_train_gauss_bwd_f32(const float* p, int32_t ldp, const float* eps, const float* dz, int32_t lddz, const float* dldj, float* dp, int32_t lddp,
-                           int32_t rows, int32_t nz, void* stream);
+                           int32_t rows, int32_t nz, float clamp, void* stream);
+int fc_train_normlp_fwd_f32(const float* v, int32_t ldv, const float* p, int32_t ldp, float* out, int32_t rows, int32_t nz, float clamp, void* stream);
+int fc_train_normlp_bwd_f32(const float* v, int32_t ldv, const float* p, int32_t ldp, const float* g, float* dv, int32_t lddv, float* dp, int32_t lddp,
+                            int32_t rows, int32_t nz, float clamp, void* stream);
 int fc_train_base_fwd_f32(const float* x, int32_t ldx, float* out, int32_t rows, int32_t width, void* stream);
 int fc_train_base_bwd_f32(const float* x, int32_t ldx, const float* g, float* dx, int32_t lddx, int32_t rows, int32_t width, void* stream);
 size_t fc_train_colsum_ws_bytes(int32_t cols, int32_t rows);

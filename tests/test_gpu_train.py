@@ -222,6 +222,8 @@ def _train_step(fx, cfg, md, fp16=True):
     e0, e1, ex = fx.t("extract_0").to(DEV), fx.t("extract_1").to(DEV), fx.t("extra")
     with torch.no_grad():
         ctx = md["input_embedder"](e0[:, :, :Din])
+    if ctx.dim() == 2:                                               # global embedder: one vector per scene, repeated per target point
+        ctx = ctx[:, None, :].expand(-1, e1.shape[1], -1).contiguous()
     ctx = ctx.detach().requires_grad_(True)
     x = e1[:, :, :Din].clone().requires_grad_(True)
     extra = None if ex is None else ex.to(DEV)[:, None, :].expand(-1, e1.shape[1], -1)
@@ -234,7 +236,7 @@ def _train_step(fx, cfg, md, fp16=True):
     return loss, lp, x, ctx
 
 
-@pytest.mark.parametrize("case", ["tiny_spline_relu", "tiny_affine", "spline_L2"])
+@pytest.mark.parametrize("case", ["tiny_spline_relu", "tiny_affine", "spline_L2", "tiny_cif", "tiny_global_extra"])
 def test_flow_backward_matches_reference_gradients(case):
     """loss.backward() through the HIP training path against the gradients the REFERENCE produced for the same weights, inputs and
     noise (tests/golden/grad_*.npz, eval mode): every flow parameter through sum / L1 / random projection / first entries, and
@@ -248,7 +250,10 @@ def test_flow_backward_matches_reference_gradients(case):
     gnorm = float(z["eval/grad_norm"])
     dx_err = np.abs(x.grad.cpu().double().numpy() - z["eval/d_extract_1"]).max() / max(1e-12, np.abs(z["eval/d_extract_1"]).max())
     names = [n for n in json.loads(bytes(z["names_json"]).decode())["eval"] if n.startswith("flow/")]
-    params = dict(md["flow"].named_parameters())
+    params = {}
+    for n, p_ in md["flow"].named_parameters():
+        params[n] = p_
+        params[n.replace(".augmenter.noise_dist.", ".slicer.noise_dist.")] = p_      # CIFblock: ONE ConditionalNormal under two names
     # the same step through the pinned oracle in fp32 (eager PyTorch = the arithmetic the reference itself trains in): its distance
     # from the fp64 reference gradients is the conditioning of the problem, and the yardstick for the HIP path
     c = fx.derived_cfg()
@@ -272,14 +277,16 @@ def test_flow_backward_matches_reference_gradients(case):
         want = z["eval/" + key]
         scale = max(want[1], 1e-6 * gnorm)
         err = np.abs(summary(params[n].grad, key) - want).max() / scale
-        err32 = np.abs(summary(sd32[n].grad, key) - want).max() / scale
+        err32 = np.abs(summary(sd32[n.replace(".slicer.noise_dist.", ".augmenter.noise_dist.")].grad, key) - want).max() / scale
         worst32 = max(worst32, err32)
         assert err < 1e-3, (key, err, err32)
         if err > worst:
             worst, worst_name = err, key
     print(f"{case}: loss {loss.item():.6f} (ref {float(z['eval/loss']):.6f}); d extract_1 rel err {dx_err:.1e}; {len(names)} flow parameter "
           f"gradients, worst error / L1 norm {worst:.1e} ({worst_name}); fp32 oracle's worst {worst32:.1e}")
-    assert dx_err < 2e-4 and worst < 3.0 * worst32 + 2e-5
+    # (+1e-4: tensors whose exact gradient is zero -- q-side weights under a context of identical keys, global embedder -- hold only
+    #  rounding noise, measured against the 1e-6 |g| floor above)
+    assert dx_err < 2e-4 and worst < 3.0 * worst32 + 1e-4
 
 
 def test_flow_backward_with_extra_context_matches_oracle_autograd():
