@@ -59,3 +59,107 @@ def sharded_inner_loop(batch, models_dict, config, eps=None, group=None):
     _, lp, _ = inner_loop(local, models_dict, config, eps=eps_local)
     loss, bpd = global_loss_bpd(lp, config["input_dim"], group)
     return loss, lp, bpd
+
+
+# ---------------------------------------------------------------- training: the one real exchange step
+class GradientReducer:
+    """Bucketed SUM all-reduce of parameter gradients, overlapped with backward (one process per GPU; "nccl" = RCCL over xGMI).
+
+    Buckets are filled in REVERSE parameter order: the flow's layers finish their backward last-to-first, so a bucket's all-reduce
+    starts as soon as its last gradient has been accumulated (post-accumulate-grad hooks) while earlier layers are still being
+    differentiated.  xGMI is point-to-point (ring collectives are per-link bound), so buckets are large: 32 MB by default, i.e.
+    about 45 collectives for the 369 M fp32 gradients of the spline flow.  The reduction is a SUM: each rank differentiates
+    -sum(log_prob_local) / n_global_points (`local_loss`), so the summed gradients are those of the global mean loss exactly,
+    also for uneven shards -- what nn.DataParallel (model_initialization.py:186-188) computes by gathering outputs on one device.
+    """
+
+    def __init__(self, params, bucket_bytes=32 << 20, group=None):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.reset()
+
+    def reset(self):
+        self.pending = [len(b) for b in self.buckets]
+        self.inflight = [None] * len(self.buckets)
+
+    def _launch(self, i):
+        b = self.buckets[i]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
+        work = dist.all_reduce(flat, group=self.group, async_op=True)
+        self.inflight[i] = (flat, work)
+
+    def _on_grad(self, p):
+        i = self.bucket_of[id(p)]
+        self.pending[i] -= 1
+        if self.pending[i] == 0:
+            self._launch(i)
+
+    def finish(self):
+        """Waits for every bucket (launching those whose parameters received no gradient this step, as zeros, so that all ranks
+        issue the same collectives) and writes the summed gradients back."""
+        for i, b in enumerate(self.buckets):
+            if self.inflight[i] is None:
+                self._launch(i)
+            flat, work = self.inflight[i]
+            work.wait()
+            off = 0
+            for p in b:
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(flat[off:off + n].view_as(p))
+                off += n
+        self.reset()
+
+    def remove(self):
+        for h in self.hooks:
+            h.remove()
+
+
+def local_loss(log_prob_local, n_global_points):
+    """This rank's share of the global mean loss: summed over ranks it equals -mean over ALL points."""
+    return -log_prob_local.sum() / n_global_points
+
+
+def sharded_training_step(batch, models_dict, config, reducer, optimizer=None, eps=None, grad_clip=None, group=None):
+    """train.py:108-120 over a GLOBAL batch sharded by scenes: every rank differentiates its scenes through the HIP training path,
+    gradients are summed by `reducer` (bucketed, overlapped with backward), then clip_grad_norm_ / optimizer.step() run identically
+    on every rank.  Returns (global loss, local log_prob, global bpd, grad_norm)."""
+    from .model_initialization import inner_loop
+    from . import train_ops as T
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_bounds(batch[0].shape[0], rank, world)
+    local = shard_batch(batch, rank, world)
+    eps_local = None if eps is None else [e[lo:hi] for e in eps]
+    n_global = batch[1].shape[0] * batch[1].shape[1]
+    params = reducer.params
+    for fp16 in (True, False):
+        for p in params:
+            p.grad = None
+        reducer.reset()
+        with T.step_guard(fp16=fp16, device=local[1].device) as guard:
+            _, lp, _ = inner_loop(local, models_dict, config, eps=eps_local)
+            local_loss(lp, n_global).backward()
+            over = torch.tensor([1.0 if guard.overflowed() else 0.0], device=lp.device)
+        reducer.finish()
+        dist.all_reduce(over, group=group)                   # every rank repeats the step if ANY rank left the fp16 range
+        if over.item() == 0.0:
+            break
+    loss, bpd = global_loss_bpd(lp.detach(), config["input_dim"], group)
+    clip = config.get("grad_clip_val") if grad_clip is None else grad_clip
+    norm = torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], max_norm=clip if clip else float("inf"))
+    if optimizer is not None:
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+    return loss, lp.detach(), bpd, norm
