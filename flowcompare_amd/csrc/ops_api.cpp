@@ -22,7 +22,7 @@ struct TmpBuf {
     catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; } \
     return FC_OK;
 
-namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; }
+namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }
 
 extern "C" {
@@ -38,6 +38,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 9) fc::g_limb_chain = value;
     else if (key == 10) fc::g_lnq_fold = value;
     else if (key == 11) fc::g_train_wgrad16 = value;
+    else if (key == 12) fc::g_train_attn16 = value;
     else return FC_ERR_INVALID;
     return FC_OK;
 }

@@ -206,6 +206,266 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdParams p) {
             }
 }
 
+// ================================================================ the same two kernels on the split-fp16 loop (head dim 64)
+// Operands as fp16 limbs (x ~ hi + lo'/2048, gemm.hip), 3 x v_mfma_f32_32x32x16_f16 per product block: hi.hi into `main`, hi.lo' and lo'.hi into
+// `cross`.  K / V (dq kernel) and Q / dO (dk/dv kernel) tiles are converted once per tile while they are staged into LDS, row-major
+// [32 rows][hi 64 | lo' 64]; a product that contracts over the head dim reads them as they lie (16 bytes per lane), a product that
+// contracts over the tile's rows reads them through ds_read_b64_tr_b16 (attention.hip, train.hip), whose row order per lane,
+// {4h..4h+3, 8+4h..8+4h+3} + 16 j, is exactly the row order of accumulator registers 8j..8j+7 -- so P^T / dS^T go from the
+// accumulators into the next MFMA's B operand after a limb split only.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+constexpr int A16_PITCH = 256 + 16;        // bytes per staged row: [hi 64 halfs | lo' 64 halfs] + pad
+
+__device__ __forceinline__ void split8(const float* v, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = (_Float16)v[i];
+        lo[i] = (_Float16)((v[i] - (float)hi[i]) * 2048.0f);
+    }
+}
+// 32 x 64 fp32 rows (row stride ld) -> limbs in LDS; rows >= valid come out as zeros.  256 threads, 8 consecutive columns each.
+__device__ __forceinline__ float stage_limbs(const float* __restrict__ src, int ld, int row0, int valid, char* dst, int tid) {
+    const int r = tid >> 3, c = (tid & 7) * 8;
+    float v[8];
+    const bool ok = row0 + r < valid;
+    const float4 a = ok ? *reinterpret_cast<const float4*>(src + (size_t)(row0 + r) * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b = ok ? *reinterpret_cast<const float4*>(src + (size_t)(row0 + r) * ld + c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    f16x8 hi, lo;
+    split8(v, hi, lo);
+    *reinterpret_cast<f16x8*>(dst + r * A16_PITCH + c * 2) = hi;
+    *reinterpret_cast<f16x8*>(dst + r * A16_PITCH + 128 + c * 2) = lo;
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(v[i]));
+    return m;
+}
+#define FC_TR16(PTR_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(PTR_))
+#define FC_TR16x2(PTR_) __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR16(PTR_), FC_TR16((PTR_) + 8 * A16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7))
+#define FC_MMA3(MAIN_, CROSS_, AH_, AL_, BH_, BL_)                                   \
+    MAIN_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH_, BH_, MAIN_, 0, 0, 0);        \
+    CROSS_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH_, BL_, CROSS_, 0, 0, 0);      \
+    CROSS_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL_, BH_, CROSS_, 0, 0, 0);
+
+__global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int* __restrict__ ovf) {
+    constexpr int DH = 64;
+    __shared__ __attribute__((aligned(16))) char sK[32 * A16_PITCH];
+    __shared__ __attribute__((aligned(16))) char sV[32 * A16_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int qrow = blockIdx.x * 128 + wave * 32 + li;
+    const bool qok = qrow < p.N;
+    const size_t grow = (size_t)b * p.N + (qok ? qrow : 0);
+    const float* kb = p.k + (size_t)b * p.M * p.ldk;
+    const float* vb = p.v + (size_t)b * p.M * p.ldv;
+    // this lane's query row as B operands: step ds covers head dims 16 ds + 8 h .. + 7
+    f16x8 Qh[4], Ql[4], Gh[4], Gl[4];
+    float dsum = 0.f, amax = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+        float qv[8], gv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = 16 * ds + 8 * h + i;
+            qv[i] = qok ? p.q[grow * p.ldq + d] : 0.f;
+            gv[i] = qok ? p.dout[grow * p.lddo + d] : 0.f;
+            dsum += gv[i] * (qok ? p.o[grow * p.ldo + d] : 0.f);
+            amax = fmaxf(amax, fmaxf(fabsf(qv[i]), fabsf(gv[i])));
+        }
+        split8(qv, Qh[ds], Ql[ds]);
+        split8(gv, Gh[ds], Gl[ds]);
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    const int ntiles = (p.M + 31) / 32;
+    const int a_off = li * A16_PITCH + 16 * h;                        // row li, 8 halfs at head dim 8 h of a 16-dim step
+    const int tr_off = (4 * h + ((lane & 15) >> 2)) * A16_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    // ---- pass A: log-sum-exp per query
+    float m = -INFINITY, l = 0.f;
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        amax = fmaxf(amax, stage_limbs(kb, p.ldk, t * 32, p.M, sK, tid));
+        __syncthreads();
+        f32x16 sm, sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; }
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(sK + a_off + 32 * ds), kl = *reinterpret_cast<const f16x8*>(sK + a_off + 32 * ds + 128);
+            FC_MMA3(sm, sc, kh, kl, Qh[ds], Ql[ds])
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool kok = t * 32 + acc_row(r, h) < p.M;
+            sm[r] = kok ? (sm[r] + sc[r] * (1.0f / 2048.0f)) * p.scale : -INFINITY;
+            tmax = fmaxf(tmax, sm[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        float ts = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ts += expf(sm[r] - mn);
+        ts += __shfl_xor(ts, 32, 64);
+        l = l * expf(m - mn) + ts;
+        m = mn;
+    }
+    const float lse = m + logf(l);
+    if (qok && h == 0) { p.lse[grow] = lse; p.dvec[grow] = dsum; }
+    // ---- pass B: dQ^T[d][query] += K^T dS^T
+    f32x16 qm[2], qc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { qm[i][r] = 0.f; qc[i][r] = 0.f; }
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        stage_limbs(kb, p.ldk, t * 32, p.M, sK, tid);
+        amax = fmaxf(amax, stage_limbs(vb, p.ldv, t * 32, p.M, sV, tid));
+        __syncthreads();
+        f32x16 sm, sc, pm, pc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; pm[r] = 0.f; pc[r] = 0.f; }
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(sK + a_off + 32 * ds), kl = *reinterpret_cast<const f16x8*>(sK + a_off + 32 * ds + 128);
+            const f16x8 vh = *reinterpret_cast<const f16x8*>(sV + a_off + 32 * ds), vl = *reinterpret_cast<const f16x8*>(sV + a_off + 32 * ds + 128);
+            FC_MMA3(sm, sc, kh, kl, Qh[ds], Ql[ds])
+            FC_MMA3(pm, pc, vh, vl, Gh[ds], Gl[ds])
+        }
+        float dsv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool kok = t * 32 + acc_row(r, h) < p.M;
+            const float pr = kok ? expf((sm[r] + sc[r] * (1.0f / 2048.0f)) * p.scale - lse) : 0.f;
+            dsv[r] = pr * ((pm[r] + pc[r] * (1.0f / 2048.0f)) - dsum) * p.scale;          // dS^T[key][query]
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f16x8 sh, sl;
+            split8(dsv + 8 * j, sh, sl);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* pk = sK + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
+                const f16x8 kh = FC_TR16x2(pk), kl = FC_TR16x2(pk + 128);
+                FC_MMA3(qm[i], qc[i], kh, kl, sh, sl)
+            }
+        }
+    }
+    if (amax >= 65504.0f || amax != amax) atomicOr(ovf, 1);
+    if (qok)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p.dq[grow * p.lddq + i * 32 + acc_row(r, h)] = qm[i][r] + qc[i][r] * (1.0f / 2048.0f);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd16_dkv_kernel(AttnBwdParams p, int* __restrict__ ovf) {
+    __shared__ __attribute__((aligned(16))) char sQ[32 * A16_PITCH];
+    __shared__ __attribute__((aligned(16))) char sG[32 * A16_PITCH];
+    __shared__ float sLse[32];
+    __shared__ float sD[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int krow = blockIdx.x * 128 + wave * 32 + li;
+    const bool kok = krow < p.M;
+    const size_t gk = (size_t)b * p.M + (kok ? krow : 0);
+    f16x8 Kh[4], Kl[4], Vh[4], Vl[4];
+    float amax = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+        float kv[8], vv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = 16 * ds + 8 * h + i;
+            kv[i] = kok ? p.k[gk * p.ldk + d] : 0.f;
+            vv[i] = kok ? p.v[gk * p.ldv + d] : 0.f;
+            amax = fmaxf(amax, fmaxf(fabsf(kv[i]), fabsf(vv[i])));
+        }
+        split8(kv, Kh[ds], Kl[ds]);
+        split8(vv, Vh[ds], Vl[ds]);
+    }
+    f32x16 km[2], kc[2], vm[2], vc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { km[i][r] = 0.f; kc[i][r] = 0.f; vm[i][r] = 0.f; vc[i][r] = 0.f; }
+    const int ntiles = (p.N + 31) / 32;
+    const size_t q0 = (size_t)b * p.N;
+    const int a_off = li * A16_PITCH + 16 * h;
+    const int tr_off = (4 * h + ((lane & 15) >> 2)) * A16_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        amax = fmaxf(amax, stage_limbs(p.q + q0 * p.ldq, p.ldq, t * 32, p.N, sQ, tid));
+        amax = fmaxf(amax, stage_limbs(p.dout + q0 * p.lddo, p.lddo, t * 32, p.N, sG, tid));
+        if (tid < 32) {
+            const int qi = t * 32 + tid;
+            sLse[tid] = qi < p.N ? p.lse[q0 + qi] : INFINITY;        // exp(s - inf) = 0: queries past the end contribute nothing
+            sD[tid] = qi < p.N ? p.dvec[q0 + qi] : 0.f;
+        }
+        __syncthreads();
+        f32x16 sm, sc, pm, pc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; pm[r] = 0.f; pc[r] = 0.f; }
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            const f16x8 qh = *reinterpret_cast<const f16x8*>(sQ + a_off + 32 * ds), ql = *reinterpret_cast<const f16x8*>(sQ + a_off + 32 * ds + 128);
+            const f16x8 gh = *reinterpret_cast<const f16x8*>(sG + a_off + 32 * ds), gl = *reinterpret_cast<const f16x8*>(sG + a_off + 32 * ds + 128);
+            FC_MMA3(sm, sc, qh, ql, Kh[ds], Kl[ds])                      // S[query][key]
+            FC_MMA3(pm, pc, gh, gl, Vh[ds], Vl[ds])                      // dP[query][key]
+        }
+        float pv[16], dsv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = acc_row(r, h);
+            const float pr = kok ? expf((sm[r] + sc[r] * (1.0f / 2048.0f)) * p.scale - sLse[qi]) : 0.f;
+            pv[r] = pr;
+            dsv[r] = pr * ((pm[r] + pc[r] * (1.0f / 2048.0f)) - sD[qi]) * p.scale;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f16x8 ph, pl, sh, sl;
+            split8(pv + 8 * j, ph, pl);
+            split8(dsv + 8 * j, sh, sl);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* pg = sG + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
+                const char* pq = sQ + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
+                const f16x8 gh = FC_TR16x2(pg), gl = FC_TR16x2(pg + 128);
+                const f16x8 qh = FC_TR16x2(pq), ql = FC_TR16x2(pq + 128);
+                FC_MMA3(vm[i], vc[i], gh, gl, ph, pl)                    // dV^T[d][key] += dO^T P
+                FC_MMA3(km[i], kc[i], qh, ql, sh, sl)                    // dK^T[d][key] += Q^T dS
+            }
+        }
+    }
+    if (amax >= 65504.0f || amax != amax) atomicOr(ovf, 1);
+    if (kok)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p.dk[gk * p.lddk + i * 32 + acc_row(r, h)] = km[i][r] + kc[i][r] * (1.0f / 2048.0f);
+                p.dv[gk * p.lddv + i * 32 + acc_row(r, h)] = vm[i][r] + vc[i][r] * (1.0f / 2048.0f);
+            }
+}
+#undef FC_MMA3
+#undef FC_TR16x2
+#undef FC_TR16
+
+int g_train_attn16 = 1;       // tuning knob (fc_debug_set 12): attention backward on the split-fp16 loop inside a guard scope (head dim 64)
+
+static void launch_attn_bwd16(const AttnBwdParams& p, int B, int* ovf, hipStream_t s) {
+    const double fl = 2.0 * B * (double)p.N * p.M * 64;
+    {
+        ProfScope ps("fc::attn_bwd16_dq_kernel", 4.0 * fl, 0.0, s);
+        hipLaunchKernelGGL(attn_bwd16_dq_kernel, dim3((p.N + 127) / 128, B), dim3(256), 0, s, p, ovf);
+        FC_HIP(hipGetLastError());
+    }
+    ProfScope ps("fc::attn_bwd16_dkv_kernel", 4.0 * fl, 0.0, s);
+    hipLaunchKernelGGL(attn_bwd16_dkv_kernel, dim3((p.M + 127) / 128, B), dim3(256), 0, s, p, ovf);
+    FC_HIP(hipGetLastError());
+}
+
 template <int DH>
 static void launch_attn_bwd(const AttnBwdParams& p, int B, hipStream_t s) {
     const double fl = 2.0 * B * (double)p.N * p.M * DH;
@@ -257,14 +517,16 @@ int fc_train_attention_fwd_f32(const float* q, int32_t ldq, const float* k, int3
 
 int fc_train_attention_bwd_f32(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* out, int32_t ldo,
                                const float* dout, int32_t lddo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv, int32_t lddv,
-                               float* stats, int32_t B, int32_t N, int32_t M, int32_t D, float scale, void* stream) {
+                               float* stats, int32_t B, int32_t N, int32_t M, int32_t D, float scale, int32_t* ovf, void* stream) {
     FC_API_BEGIN
     if (B < 1 || N < 1 || M < 1 || (D != 32 && D != 64)) throw Error(FC_ERR_UNSUPPORTED, "fc_train_attention_bwd_f32: head dim (padded) must be 32 or 64");
     check_mat(q, ldq, D, "q"); check_mat(k, ldk, D, "k"); check_mat(v, ldv, D, "v"); check_mat(out, ldo, D, "out"); check_mat(dout, lddo, D, "dout");
     check_mat(dq, lddq, D, "dq"); check_mat(dk, lddk, D, "dk"); check_mat(dv, lddv, D, "dv");
     if (!stats) throw Error(FC_ERR_INVALID, "fc_train_attention_bwd_f32: stats scratch [2 * B * N] is required");
     AttnBwdParams p{q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, dq, lddq, dk, lddk, dv, lddv, stats, stats + (size_t)B * N, N, M, scale};
-    if (D == 32) launch_attn_bwd<32>(p, B, (hipStream_t)stream); else launch_attn_bwd<64>(p, B, (hipStream_t)stream);
+    if (D == 64 && ovf && g_train_attn16) launch_attn_bwd16(p, B, (int*)ovf, (hipStream_t)stream);
+    else if (D == 32) launch_attn_bwd<32>(p, B, (hipStream_t)stream);
+    else launch_attn_bwd<64>(p, B, (hipStream_t)stream);
     FC_API_END
 }
 

@@ -236,7 +236,7 @@ class AttentionFn(torch.autograd.Function):
         with torch.cuda.device(q.device):
             engine._check(L.fc_train_attention_bwd_f32(engine._ptr(q), D, engine._ptr(k), D, engine._ptr(v), D, engine._ptr(out), D,
                                                        engine._ptr(dout), D, engine._ptr(dq), D, engine._ptr(dk), D, engine._ptr(dv), D,
-                                                       engine._ptr(stats), B, N, M, D, ctypes.c_float(scale), engine._stream()))
+                                                       engine._ptr(stats), B, N, M, D, ctypes.c_float(scale), _flag_ptr(), engine._stream()))
         return dq, dk, dv, None, None, None, None
 
 
