@@ -356,13 +356,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // dW[n][k_off + k] (=|+=) sum_s part[s][n][k]   for n < N, k < k_true: fixed summation order
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int part_rows, int part_ld, float* __restrict__ dW, int N, int K,
-                                    int k_off, int k_true, int accumulate) {
-    const size_t total = (size_t)N * k_true;
+                                    int k_off, int k_true, int accumulate, const float* __restrict__ colpart, int colpart_ld, float* __restrict__ db) {
+    // entries [0, N k_true) are dW, entries [N k_true, N k_true + N) the bias gradient (column partials of the same launch);
+    // the S partials are summed in chunk order with 8 independent loads in flight
+    const size_t nw = (size_t)N * k_true, total = nw + (db ? N : 0);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int n = (int)(i / k_true), k = (int)(i % k_true);
+        const float* src;
+        size_t stride;
+        float* dst;
+        if (i < nw) {
+            const int n = (int)(i / k_true), k = (int)(i % k_true);
+            src = part + (size_t)n * part_ld + k; stride = (size_t)part_rows * part_ld; dst = dW + (size_t)n * K + k_off + k;
+        } else {
+            const int n = (int)(i - nw);
+            src = colpart + n; stride = colpart_ld; dst = db + n;
+        }
         float s = 0.f;
-        for (int c = 0; c < S; ++c) s += part[((size_t)c * part_rows + n) * part_ld + k];
-        float* dst = dW + (size_t)n * K + k_off + k;
+        int c = 0;
+        for (; c + 8 <= S; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(c + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; c < S; ++c) s += src[(size_t)c * stride];
         *dst = accumulate ? *dst + s : s;
     }
 }
@@ -408,7 +426,15 @@ __global__ void colsum_reduce_kernel(const float* __restrict__ part, int S, int 
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     float s = 0.f;
-    for (int i = 0; i < S; ++i) s += part[(size_t)i * part_ld + c];
+    int i = 0;
+    for (; i + 8 <= S; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(i + u) * part_ld + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; i < S; ++i) s += part[(size_t)i * part_ld + c];
     out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -560,17 +586,13 @@ int fc_train_linear_wgrad_f32(int32_t N, const int32_t* seg_widths, int32_t nseg
             }
             const size_t total = (size_t)L.N * L.seg[i];
             ProfScope ps("fc::wgrad_reduce_kernel", 0.0, (double)total * 4.0 * (w.S + 1), s);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, part, w.S, w.n128, k128, dW, L.N, L.K, k_off,
-                               L.seg[i], accumulate);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total + L.N, 256)), dim3(256), 0, s, part, w.S, w.n128, k128, dW, L.N, L.K, k_off,
+                               L.seg[i], accumulate, cpart, w.n128, (db && i == 0) ? db : nullptr);
             FC_HIP(hipGetLastError());
             k_off += L.seg[i];
         }
     }
-    if (db && dW) {
-        // column partials came out of the first segment's wgrad launch: [S][n128]
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((L.N + 255) / 256), dim3(256), 0, s, cpart, w.S, w.n128, db, L.N, accumulate);
-        FC_HIP(hipGetLastError());
-    } else if (db) {
+    if (db && !dW) {
         ProfScope ps("fc::colsum_kernel", 0.0, (double)rows * L.N * 4.0, s);
         hipLaunchKernelGGL(colsum_kernel, dim3((L.N + 255) / 256, w.S2), dim3(256), 0, s, du, ldu, L.N, rows, w.chunk2, cpart, L.N_pad);
         FC_HIP(hipGetLastError());

@@ -75,6 +75,22 @@ def _ws(nbytes, device):
         return t
 
 
+def _panel_out(rows_pad, cols, rows, device):
+    """Uninitialised [rows_pad, cols] panel whose pad ROWS are zeroed (the row-wise kernels write `rows` rows, pad columns included);
+    at the bench sizes rows == rows_pad and nothing is filled."""
+    t = torch.empty(rows_pad, cols, dtype=torch.float32, device=device)
+    if rows < rows_pad:
+        t[rows:].zero_()
+    return t
+
+
+def _vec_out(rows_pad, rows, device):
+    t = torch.empty(rows_pad, dtype=torch.float32, device=device)
+    if rows < rows_pad:
+        t[rows:].zero_()
+    return t
+
+
 def _segs(widths):
     return (ctypes.c_int32 * len(widths))(*widths)
 
@@ -215,7 +231,7 @@ class AttentionFn(torch.autograd.Function):
             if t.shape[0] < rows or t.shape[1] != D:
                 raise RuntimeError("AttentionFn: panel smaller than B * points, or head dims differ")
         dev = q.device
-        out = torch.zeros_like(q)
+        out = _panel_out(q.shape[0], D, B * N, dev)
         with torch.cuda.device(dev):
             nb = L.fc_train_attention_ws_bytes(B, N, M, D)
             ws = _ws(nb, dev) if _Step.flag is not None else None
@@ -231,7 +247,8 @@ class AttentionFn(torch.autograd.Function):
         q, k, v, out = ctx.saved_tensors
         B, N, M, D, scale = ctx.meta
         dout = dout.contiguous()
-        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        dq = _panel_out(q.shape[0], D, B * N, q.device)
+        dk, dv = _panel_out(k.shape[0], D, B * M, q.device), _panel_out(k.shape[0], D, B * M, q.device)
         stats = torch.empty(2 * B * N, dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
             engine._check(L.fc_train_attention_bwd_f32(engine._ptr(q), D, engine._ptr(k), D, engine._ptr(v), D, engine._ptr(out), D,
@@ -253,8 +270,8 @@ class SplineFn(torch.autograd.Function):
         L = engine.lib()
         _check_panel(x2, d2)
         _check_panel(params, d2 * (3 * K + 1))
-        y2 = torch.zeros_like(x2)
-        ldj = torch.zeros(x2.shape[0], dtype=torch.float32, device=x2.device)
+        y2 = _panel_out(x2.shape[0], _round_up(d2, 32), rows, x2.device)
+        ldj = _vec_out(x2.shape[0], rows, x2.device)
         with torch.cuda.device(x2.device):
             engine._check(L.fc_train_rqspline_fwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(params), params.shape[1], engine._ptr(y2),
                                                       y2.shape[1], engine._ptr(ldj), rows, d2, K, engine._stream()))
@@ -268,7 +285,9 @@ class SplineFn(torch.autograd.Function):
         x2, params = ctx.saved_tensors
         rows, d2, K = ctx.meta
         dy2, dldj = dy2.contiguous(), dldj.contiguous()
-        dx2, dparams = torch.zeros_like(x2), torch.zeros_like(params)
+        dx2 = _panel_out(x2.shape[0], x2.shape[1], rows, x2.device) if x2.shape[1] == _round_up(d2, 32) else torch.zeros_like(x2)
+        dparams = (_panel_out(params.shape[0], params.shape[1], rows, x2.device) if params.shape[1] == _round_up(d2 * (3 * K + 1), 32)
+                   else torch.zeros_like(params))
         with torch.cuda.device(x2.device):
             engine._check(L.fc_train_rqspline_bwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(params), params.shape[1], engine._ptr(dy2),
                                                       dy2.shape[1], engine._ptr(dldj), engine._ptr(dx2), dx2.shape[1], engine._ptr(dparams),
@@ -298,7 +317,7 @@ class LayerNormFn(torch.autograd.Function):
         L = engine.lib()
         width = gamma.shape[0]
         _check_panel(x, width)
-        y = torch.zeros(x.shape[0], _round_up(width, 32), dtype=torch.float32, device=x.device)
+        y = _panel_out(x.shape[0], _round_up(width, 32), rows, x.device)
         stats = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         with torch.cuda.device(x.device):
@@ -342,8 +361,8 @@ class AffineFn(torch.autograd.Function):
         L = engine.lib()
         _check_panel(x2, d2)
         _check_panel(st, 2 * d2)
-        y2 = torch.zeros(x2.shape[0], _round_up(d2, 32), dtype=torch.float32, device=x2.device)
-        ldj = torch.zeros(x2.shape[0], dtype=torch.float32, device=x2.device)
+        y2 = _panel_out(x2.shape[0], _round_up(d2, 32), rows, x2.device)
+        ldj = _vec_out(x2.shape[0], rows, x2.device)
         with torch.cuda.device(x2.device):
             engine._check(L.fc_train_affine_fwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(st), st.shape[1], engine._ptr(y2), y2.shape[1],
                                                     engine._ptr(ldj), rows, d2, scale_fn, engine._stream()))
@@ -357,7 +376,8 @@ class AffineFn(torch.autograd.Function):
         x2, st = ctx.saved_tensors
         rows, d2, scale_fn = ctx.meta
         dy2, dldj = dy2.contiguous(), dldj.contiguous()
-        dx2, dst = torch.zeros_like(x2), torch.zeros_like(st)
+        dx2 = _panel_out(x2.shape[0], x2.shape[1], rows, x2.device) if x2.shape[1] == _round_up(d2, 32) else torch.zeros_like(x2)
+        dst = _panel_out(st.shape[0], st.shape[1], rows, x2.device) if st.shape[1] == _round_up(2 * d2, 32) else torch.zeros_like(st)
         with torch.cuda.device(x2.device):
             engine._check(L.fc_train_affine_bwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(st), st.shape[1], engine._ptr(dy2), dy2.shape[1],
                                                     engine._ptr(dldj), engine._ptr(dx2), dx2.shape[1], engine._ptr(dst), dst.shape[1], rows, d2,
@@ -378,8 +398,8 @@ class GaussDrawFn(torch.autograd.Function):
         L = engine.lib()
         _check_panel(p, 2 * nz)
         eps = eps.to(torch.float32).contiguous()
-        z = torch.zeros(p.shape[0], _round_up(nz, 32), dtype=torch.float32, device=p.device)
-        ldj = torch.zeros(p.shape[0], dtype=torch.float32, device=p.device)
+        z = _panel_out(p.shape[0], _round_up(nz, 32), rows, p.device)
+        ldj = _vec_out(p.shape[0], rows, p.device)
         with torch.cuda.device(p.device):
             engine._check(L.fc_train_gauss_fwd_f32(engine._ptr(p), p.shape[1], engine._ptr(eps), engine._ptr(z), z.shape[1], engine._ptr(ldj), rows, nz,
                                                    ctypes.c_float(clamp), engine._stream()))
@@ -393,7 +413,7 @@ class GaussDrawFn(torch.autograd.Function):
         p, eps = ctx.saved_tensors
         rows, nz, clamp = ctx.meta
         dz, dldj = dz.contiguous(), dldj.contiguous()
-        dp = torch.zeros_like(p)
+        dp = _panel_out(p.shape[0], p.shape[1], rows, p.device) if p.shape[1] == _round_up(2 * nz, 32) else torch.zeros_like(p)
         with torch.cuda.device(p.device):
             engine._check(L.fc_train_gauss_bwd_f32(engine._ptr(p), p.shape[1], engine._ptr(eps), engine._ptr(dz), dz.shape[1], engine._ptr(dldj),
                                                    engine._ptr(dp), dp.shape[1], rows, nz, ctypes.c_float(clamp), engine._stream()))
@@ -412,7 +432,7 @@ class NormalLogProbFn(torch.autograd.Function):
         L = engine.lib()
         _check_panel(v, nz)
         _check_panel(p, 2 * nz)
-        out = torch.zeros(v.shape[0], dtype=torch.float32, device=v.device)
+        out = _vec_out(v.shape[0], rows, v.device)
         with torch.cuda.device(v.device):
             engine._check(L.fc_train_normlp_fwd_f32(engine._ptr(v), v.shape[1], engine._ptr(p), p.shape[1], engine._ptr(out), rows, nz,
                                                     ctypes.c_float(clamp), engine._stream()))
@@ -426,7 +446,8 @@ class NormalLogProbFn(torch.autograd.Function):
         v, p = ctx.saved_tensors
         rows, nz, clamp = ctx.meta
         g = g.contiguous()
-        dv, dp = torch.zeros_like(v), torch.zeros_like(p)
+        dv = _panel_out(v.shape[0], v.shape[1], rows, v.device) if v.shape[1] == _round_up(nz, 32) else torch.zeros_like(v)
+        dp = _panel_out(p.shape[0], p.shape[1], rows, v.device) if p.shape[1] == _round_up(2 * nz, 32) else torch.zeros_like(p)
         with torch.cuda.device(v.device):
             engine._check(L.fc_train_normlp_bwd_f32(engine._ptr(v), v.shape[1], engine._ptr(p), p.shape[1], engine._ptr(g), engine._ptr(dv), dv.shape[1],
                                                     engine._ptr(dp), dp.shape[1], rows, nz, ctypes.c_float(clamp), engine._stream()))
@@ -444,7 +465,7 @@ class BaseDensityFn(torch.autograd.Function):
     def forward(ctx, x, rows, width):
         L = engine.lib()
         _check_panel(x, width)
-        out = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+        out = _vec_out(x.shape[0], rows, x.device)
         with torch.cuda.device(x.device):
             engine._check(L.fc_train_base_fwd_f32(engine._ptr(x), x.shape[1], engine._ptr(out), rows, width, engine._stream()))
         ctx.save_for_backward(x)
@@ -457,7 +478,7 @@ class BaseDensityFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         rows, width = ctx.meta
         g = g.contiguous()
-        dx = torch.zeros_like(x)
+        dx = _panel_out(x.shape[0], x.shape[1], rows, x.device) if x.shape[1] == _round_up(width, 32) else torch.zeros_like(x)
         with torch.cuda.device(x.device):
             engine._check(L.fc_train_base_bwd_f32(engine._ptr(x), x.shape[1], engine._ptr(g), engine._ptr(dx), dx.shape[1], rows, width, engine._stream()))
         return dx, None, None
