@@ -25,6 +25,7 @@ from . import modules as M
 from . import train_ops as T
 
 LOG_2PI = math.log(2.0 * math.pi)
+ACTIVATION_BUDGET_BYTES = None      # None: 55 % of the HBM available at call time; 0: checkpoint every layer (flow_log_prob)
 
 
 def _attention_block(pre, h_panel, h_width, ctx_k, ctx_v, rows, B, N, Mctx):
@@ -57,9 +58,10 @@ def _lu_weight(perm):
     return L @ U, torch.log(diag).sum()
 
 
-def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, checkpoint=True):
+def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, checkpoint=True, activation_budget_bytes=None):
     """log p(x | context) [B, N] with autograd through HIP kernels.  Arguments as Flow.log_prob (modules.py); `eps` pins the
-    augmenter noise; `checkpoint` recomputes each layer's forward during backward (only layer inputs stay resident).
+    augmenter noise; `checkpoint` recomputes a layer's forward during backward for the layers whose saved activations do not fit
+    `activation_budget_bytes` (default: 55 % of the HBM that is free at call time; 0 = checkpoint every layer).
     Call inside train_ops.step_guard() to run the split-fp16 loops with the range flag."""
     cfg = flow._config
     act = act or cfg["coupling_block_nonlinearity"]
@@ -176,6 +178,18 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
             return x1, x2, logp
         return layer
 
+    # Activation budget: HBM is 288 GB and one layer's saved activations are ~2.6 GB at 16 x 4096 points, so a good part of the stack
+    # can simply keep them; only the layers beyond the budget are checkpointed (recomputed in backward).  The first kept layer is
+    # measured (allocator growth) and that figure plans the rest.
+    budget, kept_bytes, layer_bytes = 0, 0, None
+    if checkpoint and torch.is_grad_enabled() and x.is_cuda:
+        if activation_budget_bytes is None:
+            activation_budget_bytes = ACTIVATION_BUDGET_BYTES
+        if activation_budget_bytes is None:
+            free, _total = torch.cuda.mem_get_info(x.device)
+            reusable = torch.cuda.memory_reserved(x.device) - torch.cuda.memory_allocated(x.device)      # cached by the allocator, free to us
+            activation_budget_bytes = int(0.55 * (free + reusable))
+        budget = int(activation_budget_bytes)
     i = 1
     while i < len(transforms):
         blk = transforms[i]
@@ -209,10 +223,18 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
             e = eps.pop(0) if eps else torch.randn(B, N, nzc, device=x.device)
             e = e.reshape(rows, nzc)
         fn = make_layer(blk, an, perm)
-        if checkpoint and torch.is_grad_enabled():
-            x1, x2, logp = torch.utils.checkpoint.checkpoint(fn, x1, x2, logp, ctx_panel, extra_panel, e, use_reentrant=False)
-        else:
+        keep = not (checkpoint and torch.is_grad_enabled())
+        if not keep and budget > 0 and (layer_bytes is None or kept_bytes + layer_bytes <= budget):
+            keep = True                                   # this layer's activations stay resident: no recompute in backward
+        if keep:
+            before = torch.cuda.memory_allocated(x.device) if budget > 0 else 0
             x1, x2, logp = fn(x1, x2, logp, ctx_panel, extra_panel, e)
+            if budget > 0:
+                grown = torch.cuda.memory_allocated(x.device) - before
+                layer_bytes = grown if layer_bytes is None else max(layer_bytes, grown)
+                kept_bytes += grown
+        else:
+            x1, x2, logp = torch.utils.checkpoint.checkpoint(fn, x1, x2, logp, ctx_panel, extra_panel, e, use_reentrant=False)
 
     # ---- base density (models/distributions.py:192-195)
     logp = logp + T.base_density(x1, rows, d1) + T.base_density(x2, rows, d2)

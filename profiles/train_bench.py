@@ -22,8 +22,11 @@ ap.add_argument("--points", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--profile", action="store_true")
+ap.add_argument("--budget-gb", type=float, default=-1.0, help="activation budget in GB (-1 = default: 55 %% of free HBM, 0 = checkpoint every layer)")
 a = ap.parse_args()
 dev = "cuda:0"
+if a.budget_gb >= 0:
+    train_flow.ACTIVATION_BUDGET_BYTES = int(a.budget_gb * 2**30)
 cfg = fa.named_config("c2_dgcnn_attn_spline", sample_size=a.points, n_flow_layers=a.layers)
 torch.manual_seed(0)
 md = fa.initialize_flow(cfg, device=dev, mode="test")
