@@ -58,6 +58,18 @@ def _lu_weight(perm):
     return L @ U, torch.log(diag).sum()
 
 
+def _actnorm_data_init(an, parts, rows):
+    """act_norm.py:27-39, 72-88: on the first training batch shift = mean and log_scale = log(unbiased std + eps) of the layer's input
+    over batch and points.  One-off, so the two reductions are torch ops on the panels.  Like the reference it REPLACES the
+    Parameter objects (an optimiser built before the first forward therefore keeps updating the old, orphaned tensors and these
+    stay at their data-dependent values -- the reference's behaviour, kept on purpose)."""
+    with torch.no_grad():
+        xcat = torch.cat([p[:rows, :w] for p, w in parts], -1)
+        an.shift = torch.nn.Parameter(xcat.mean(0, keepdim=True))
+        an.log_scale = torch.nn.Parameter(torch.log(xcat.std(0, keepdim=True) + an.eps))
+        an.initialized += 1.0
+
+
 def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, checkpoint=True, activation_budget_bytes=None):
     """log p(x | context) [B, N] with autograd through HIP kernels.  Arguments as Flow.log_prob (modules.py); `eps` pins the
     augmenter noise; `checkpoint` recomputes a layer's forward during backward for the layers whose saved activations do not fit
@@ -129,7 +141,7 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
             x2, ldj = T.affine(x2, p, rows, d2, cp.scale_fn_type)
         return x2, logp + ldj
 
-    def make_layer(blk, an, perm):
+    def make_layer(blk, an, perm, init_an, init_cif):
         cif = isinstance(blk, M.CIFblock)
 
         def layer(x1, x2, logp, ctx_panel, extra_panel, e):
@@ -149,6 +161,9 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
                 b, ldj = T.affine(b, st, rows, D, "sigmoid")
                 logp = logp + ldj
                 # ActNorm(Dc) followed by Reverse, as one Linear on (a | b) whose weight is a flipped diagonal (parameter space)
+                if init_cif:
+                    if float(blk.act_norm.initialized.item()) == 0.0:
+                        _actnorm_data_init(blk.act_norm, [(a, nz), (b, D)], rows)
                 g = torch.exp(-blk.act_norm.log_scale.reshape(-1))
                 W = torch.diag(g).flip(0)
                 bias = (-blk.act_norm.shift.reshape(-1) * g).flip(0)
@@ -164,6 +179,8 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
             # ActNorm and the permuter between layers, applied as ONE Linear on (x1 | x2)
             W, b = None, None
             if an is not None:
+                if init_an and float(an.initialized.item()) == 0.0:          # (a checkpointed recompute finds it initialised)
+                    _actnorm_data_init(an, [(x1, d1), (x2, d2)], rows)
                 g = torch.exp(-an.log_scale.reshape(-1))
                 W, b = torch.diag(g), -an.shift.reshape(-1) * g
                 logp = logp - an.log_scale.sum()
@@ -213,16 +230,17 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
             i += 1
         elif i < len(transforms) and not isinstance(transforms[i], (M.PreConditionApplier, M.CIFblock)):
             raise NotImplementedError(f"training path: permuter {type(transforms[i]).__name__} is not built yet")
-        for a_n in ([an] if an is not None else []) + ([blk.act_norm] if isinstance(blk, M.CIFblock) else []):
-            if float(a_n.initialized.item()) == 0.0:
-                raise NotImplementedError("training path: data-dependent ActNorm initialisation (act_norm.py:27-35) is not built yet; "
-                                          "load a checkpoint or set the statistics first")
+        # un-initialised ActNorm layers take their statistics from this batch, in training mode only (act_norm.py:38-39)
+        init_an = an is not None and float(an.initialized.item()) == 0.0
+        init_cif = isinstance(blk, M.CIFblock) and float(blk.act_norm.initialized.item()) == 0.0
+        if (init_an or init_cif) and not flow.training:
+            init_an = init_cif = False
         e = None
         if isinstance(blk, M.CIFblock):
             nzc = cfg["cif_latent_dim"] - D
             e = eps.pop(0) if eps else torch.randn(B, N, nzc, device=x.device)
             e = e.reshape(rows, nzc)
-        fn = make_layer(blk, an, perm)
+        fn = make_layer(blk, an, perm, init_an, init_cif)
         keep = not (checkpoint and torch.is_grad_enabled())
         if not keep and budget > 0 and (layer_bytes is None or kept_bytes + layer_bytes <= budget):
             keep = True                                   # this layer's activations stay resident: no recompute in backward

@@ -213,8 +213,29 @@ def exponential_coupling(sd, prefix, x, cond, act, algo, eps_expm, inverse=False
 
 
 # --------------------------------------------------------------------------- ActNorm / permuters
+ACTNORM_DATA_INIT = False      # set by actnorm_data_init(): the first TRAINING forward of un-initialised ActNorm layers
+
+
+class actnorm_data_init:
+    """Context manager: every ActNorm forward first sets its statistics from its input (act_norm.py:27-39, 72-88: shift = mean over
+    batch and points, log_scale = log(unbiased std + 1e-6)), writing them into the state_dict -- what the reference does on the
+    first batch when `training and not initialized`."""
+    def __enter__(self):
+        global ACTNORM_DATA_INIT
+        self.prev, ACTNORM_DATA_INIT = ACTNORM_DATA_INIT, True
+
+    def __exit__(self, *a):
+        global ACTNORM_DATA_INIT
+        ACTNORM_DATA_INIT = self.prev
+
+
 def actnorm(sd, prefix, x, inverse=False):
-    """models/act_norm.py:37-46 (eval / already initialised)."""
+    """models/act_norm.py:37-46 (already initialised, or data-dependent init inside actnorm_data_init())."""
+    if ACTNORM_DATA_INIT and not inverse:
+        with torch.no_grad():
+            flat = x.reshape(-1, x.shape[-1])
+            sd[f"{prefix}.shift"] = flat.mean(0, keepdim=True)
+            sd[f"{prefix}.log_scale"] = torch.log(flat.std(0, keepdim=True) + 1e-6)
     sh, ls = sd[f"{prefix}.shift"], sd[f"{prefix}.log_scale"]
     if inverse:
         return sh + x * torch.exp(ls)

@@ -11,6 +11,8 @@ plus the gradient w.r.t. the target points' coordinates (extract_1, dense, small
 `clip_grad_norm_` (train.py:115) computes.  A random projection pins the whole tensor: an error in any entry moves g . r.
 Two modes: "eval" (BatchNorm running statistics — the function the forward fixtures pin) and "train" (`.train()`: BatchNorm
 batch statistics in the DGCNN embedder, ActNorm already initialised, torch.utils.checkpoint recompute — numerically a no-op).
+A third record, "init", is the first training forward with every ActNorm un-initialised (act_norm.py:27-39): the statistics each
+layer sets from its input and the resulting log-probs (embedder in eval mode, as the HIP training path runs it this round).
 
     python tests/golden/gen_golden_grads.py            # writes tests/golden/grad_*.npz
 """
@@ -78,6 +80,29 @@ def grad_case(case):
         arrays[f"{mode}/grad_norm"] = np.float64(sq ** 0.5)
         info[mode] = names
         print(f"[{case}] {mode}: loss {loss.item():.6f}  |grad| {sq ** 0.5:.4e}  {len(names)} parameter tensors")
+    # ---- data-dependent ActNorm initialisation (act_norm.py:27-39): first training forward with `initialized` == 0
+    cfg = G.load_cfg(meta["cfg_name"], sample_size=meta["N"], **meta["over"])
+    md = G.build(cfg, meta["seed"], torch.float64)
+    md["flow"].train()
+    md["input_embedder"].eval()                     # the HIP training path runs the embedder frozen in eval mode this round
+    n_init = 0
+    for m in md["flow"].modules():
+        if hasattr(m, "initialized"):
+            m.initialized.zero_()
+            n_init += 1
+    if n_init:
+        G._EPS_QUEUE[:] = list(eps)
+        with torch.no_grad():
+            loss, lp, bpd = G.mi.inner_loop((e0, e1.detach(), ex), md, cfg)
+        assert not G._EPS_QUEUE
+        arrays["init/loss"] = np.float64(loss.item())
+        arrays["init/log_prob"] = lp.numpy()
+        for n, m in md["flow"].named_modules():
+            if hasattr(m, "initialized"):
+                assert float(m.initialized) == 1.0
+                arrays[f"init/{n}.shift"] = m.shift.detach().numpy()
+                arrays[f"init/{n}.log_scale"] = m.log_scale.detach().numpy()
+        print(f"[{case}] data-dependent init of {n_init} ActNorm layers: loss {loss.item():.6f}")
     arrays["names_json"] = np.frombuffer(json.dumps(info).encode(), dtype=np.uint8)
     path = os.path.join(HERE, "grad_" + case[len("e2e_"):] + ".npz")
     np.savez_compressed(path, **arrays)

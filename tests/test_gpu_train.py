@@ -361,3 +361,30 @@ def test_deep_stack_gradients_are_as_close_to_fp64_as_eager_fp32():
     d_h, d_32 = (lp.detach().cpu().double() - lp64).abs().max().item(), (lp32 - lp64).abs().max().item()
     print(f"8 layers at real widths: |g - g64| / |g64|: HIP {e_h:.2e}, fp32 oracle {e_32:.2e}; log-prob max diff: HIP {d_h:.2e}, fp32 oracle {d_32:.2e}")
     assert e_h < 3.0 * e_32 + 1e-5
+
+
+@pytest.mark.parametrize("case", ["tiny_affine", "tiny_spline_relu", "tiny_cif", "spline_L2"])
+def test_actnorm_data_dependent_init_matches_reference(case):
+    """First training forward with every ActNorm un-initialised (act_norm.py:27-39): the statistics each layer takes from its input and
+    the resulting log-probs against the reference's own first batch (tests/golden/grad_*.npz, record "init")."""
+    fx = Fixture("e2e_" + case)
+    z = np.load(os.path.join(GOLDEN, "grad_" + case + ".npz"))
+    cfg, md = _build(fx)
+    md["flow"].train()
+    old = {}
+    for n, m in md["flow"].named_modules():
+        if hasattr(m, "initialized"):
+            m.initialized.zero_()
+            old[n] = m.shift
+    loss, lp, x, ctx = _train_step(fx, cfg, md)
+    assert np.abs(lp.detach().cpu().double().numpy() - z["init/log_prob"]).max() < 2e-3
+    worst = 0.0
+    for n, m in md["flow"].named_modules():
+        if hasattr(m, "initialized"):
+            assert float(m.initialized) == 1.0 and m.shift is not old[n]          # replaced Parameter objects, like the reference
+            for leaf in ("shift", "log_scale"):
+                want = z[f"init/{n}.{leaf}"]
+                worst = max(worst, np.abs(getattr(m, leaf).detach().cpu().double().numpy() - want).max() / max(1.0, np.abs(want).max()))
+    print(f"{case}: ActNorm data-dependent init, worst statistic error {worst:.1e}; loss {loss.item():.5f} (ref {float(z['init/loss']):.5f})")
+    assert worst < 1e-4
+    md["flow"].eval()

@@ -64,3 +64,25 @@ def test_oracle_autograd_matches_reference_backward(case, mode):
         sq += float((g ** 2).sum())
     assert abs(sq ** 0.5 - float(z[f"{mode}/grad_norm"])) < 1e-8 * float(z[f"{mode}/grad_norm"])
     print(f"{case}/{mode}: {len(names)} parameter gradients, worst error / L1 norm {worst:.1e}")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_actnorm_data_init_matches_reference(case):
+    """First training forward with un-initialised ActNorm layers (act_norm.py:27-39): the statistics every layer sets from its input
+    and the resulting log-probs, against the reference's own run."""
+    fx = Fixture("e2e_" + case)
+    z = np.load(os.path.join(GOLDEN, "grad_" + case + ".npz"))
+    if "init/loss" not in z.files:
+        pytest.skip("no ActNorm layer in this configuration")
+    cfg = fx.derived_cfg()
+    sd_f, sd_e = fx.state_dicts(torch.float64)
+    e0, e1, ex = fx.t("extract_0", torch.float64), fx.t("extract_1", torch.float64), fx.t("extra", torch.float64)
+    with torch.no_grad(), O.actnorm_data_init():
+        loss, lp, _ = O.inner_loop(cfg, sd_f, sd_e, (e0, e1, ex), fx.eps(torch.float64))
+    np.testing.assert_allclose(lp.numpy(), z["init/log_prob"], rtol=1e-9, atol=1e-9)
+    n = 0
+    for key in z.files:
+        if key.startswith("init/transforms"):
+            np.testing.assert_allclose(sd_f[key[len("init/"):]].numpy(), z[key], rtol=1e-9, atol=1e-10)
+            n += 1
+    assert n >= 2
