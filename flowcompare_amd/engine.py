@@ -35,6 +35,7 @@ EXPORTS = [
     "fc_train_colsum_ws_bytes", "fc_train_colsum_f32",
     "fc_train_affine_fwd_f32", "fc_train_affine_bwd_f32", "fc_train_gauss_fwd_f32", "fc_train_gauss_bwd_f32", "fc_train_base_fwd_f32", "fc_train_base_bwd_f32",
     "fc_train_normlp_fwd_f32", "fc_train_normlp_bwd_f32",
+    "fc_train_edge_ws_bytes", "fc_train_edge_stats_f32", "fc_train_edge_fwd_f32", "fc_train_edge_bwd_prep_f32", "fc_train_edge_bwd_scatter_f32",
 ]
 
 
@@ -74,6 +75,7 @@ def lib():
         L.fc_train_linear_wgrad_ws_bytes.restype = ctypes.c_size_t
         L.fc_train_attention_ws_bytes.restype = ctypes.c_size_t
         L.fc_train_colsum_ws_bytes.restype = ctypes.c_size_t
+        L.fc_train_edge_ws_bytes.restype = ctypes.c_size_t
         if L.fc_abi_version() != ABI_VERSION:
             raise RuntimeError("libfcflow.so ABI version mismatch: rebuild with `python -m flowcompare_amd.build --force`")
         _lib = L

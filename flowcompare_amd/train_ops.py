@@ -486,3 +486,72 @@ class BaseDensityFn(torch.autograd.Function):
 
 def base_density(x, rows, width):
     return BaseDensityFn.apply(x, rows, width)
+
+
+class EdgeBNMaxFn(torch.autograd.Function):
+    """One EdgeConv level of the DGCNN embedder in training mode, after the two per-point products (csrc/train_edge.hip):
+    pq panel [rows_pad, 2C] = [P | Q] (or [rows_pad, C] = P alone when idx is None: BatchNorm1d + LeakyReLU of conv5), idx [rows, k]
+    int32 global row indices -> max_j lrelu(BN_batch(P[idx_ij] + Q[i])) as a panel [rows_pad, C].  `bn` is the BatchNorm module:
+    its running statistics are updated exactly as torch does in train mode (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, pq, gamma, beta, idx, rows, C, k, bn):
+        L = engine.lib()
+        dev = pq.device
+        has_q = idx is not None
+        ld = pq.shape[1]
+        if ld < (2 * C if has_q else C) or C % 32 != 0:
+            raise RuntimeError("EdgeBNMaxFn: panel narrower than the channels, or channel count not a multiple of 32")
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        stats = torch.empty(3 * C, dtype=torch.float32, device=dev)
+        out = _panel_out(pq.shape[0], C, rows, dev)
+        arg = torch.empty(rows, C, dtype=torch.uint8, device=dev)
+        q_ptr = ctypes.c_void_p(pq.data_ptr() + 4 * C) if has_q else ctypes.c_void_p(0)
+        with torch.cuda.device(dev):
+            s = engine._stream()
+            nb = L.fc_train_edge_ws_bytes(rows, C)
+            ws = _ws(nb, dev)
+            engine._check(L.fc_train_edge_stats_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, ctypes.c_float(bn.eps),
+                                                    engine._ptr(stats), engine._ptr(ws), ctypes.c_size_t(nb), s))
+            engine._check(L.fc_train_edge_fwd_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats), engine._ptr(g32),
+                                                  engine._ptr(b32), engine._ptr(out), C, engine._ptr(arg), s))
+        if bn.track_running_stats and bn.running_mean is not None:
+            # torch.nn.BatchNorm train-mode side effect (parameter-sized vectors): running <- (1 - m) running + m batch, unbiased variance
+            with torch.no_grad():
+                n = rows * k
+                m = bn.momentum if bn.momentum is not None else 0.1
+                bn.running_mean.mul_(1 - m).add_(stats[:C].to(bn.running_mean.dtype), alpha=m)
+                bn.running_var.mul_(1 - m).add_(stats[2 * C:].to(bn.running_var.dtype) * (n / max(n - 1, 1)), alpha=m)
+                bn.num_batches_tracked += 1
+        ctx.save_for_backward(pq, g32, b32, stats, arg, idx)
+        ctx.meta = (rows, C, k, has_q, gamma.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = engine.lib()
+        pq, g32, b32, stats, arg, idx = ctx.saved_tensors
+        rows, C, k, has_q, pdtype = ctx.meta
+        dev = pq.device
+        g = g.contiguous()
+        ld = pq.shape[1]
+        q_ptr = ctypes.c_void_p(pq.data_ptr() + 4 * C) if has_q else ctypes.c_void_p(0)
+        rows_pad = pq.shape[0]
+        t1 = torch.empty(rows_pad, C, dtype=torch.float32, device=dev)
+        t2 = torch.empty(rows_pad, C, dtype=torch.float32, device=dev)
+        dpq = torch.zeros_like(pq)                                  # dP accumulates by atomics
+        with torch.cuda.device(dev):
+            s = engine._stream()
+            engine._check(L.fc_train_edge_bwd_prep_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats), engine._ptr(g32),
+                                                       engine._ptr(b32), engine._ptr(arg), engine._ptr(g), g.shape[1], engine._ptr(t1), engine._ptr(t2),
+                                                       C, rows_pad, s))
+            dbeta, dgamma = _colsum(t1, C, rows), _colsum(t2, C, rows)
+            dq_ptr = ctypes.c_void_p(dpq.data_ptr() + 4 * C) if has_q else ctypes.c_void_p(0)
+            engine._check(L.fc_train_edge_bwd_scatter_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats),
+                                                          engine._ptr(g32), engine._ptr(arg), engine._ptr(t1), C, engine._ptr(dbeta), engine._ptr(dgamma),
+                                                          engine._ptr(dpq), ld, dq_ptr, ld, s))
+        return dpq, dgamma.to(pdtype), dbeta.to(pdtype), None, None, None, None, None
+
+
+def edge_bn_max(pq, bn, idx, rows, C, k):
+    return EdgeBNMaxFn.apply(pq, bn.weight, bn.bias, idx, rows, C, k, bn)

@@ -388,3 +388,51 @@ def test_actnorm_data_dependent_init_matches_reference(case):
     print(f"{case}: ActNorm data-dependent init, worst statistic error {worst:.1e}; loss {loss.item():.5f} (ref {float(z['init/loss']):.5f})")
     assert worst < 1e-4
     md["flow"].eval()
+
+
+@pytest.mark.parametrize("case", ["tiny_affine", "tiny_spline_relu", "spline_L2", "tiny_global_extra"])
+def test_full_training_step_matches_reference_train_mode_gradients(case):
+    """The WHOLE path in train() mode -- DGCNN embedder with BatchNorm batch statistics, flow, loss.backward() -- against the gradients
+    the reference produced in train mode for the same weights, inputs and noise (tests/golden/grad_*.npz, record "train"): every
+    embedder and flow parameter, d loss / d extract_1, and the BatchNorm running statistics torch would have after the step."""
+    from flowcompare_amd import train_embed
+    fx = Fixture("e2e_" + case)
+    z = np.load(os.path.join(GOLDEN, "grad_" + case + ".npz"))
+    cfg, md = _build(fx)
+    md["flow"].train()
+    md["input_embedder"].train()
+    Din = cfg["input_dim"]
+    e0, e1, ex = fx.t("extract_0").to(DEV), fx.t("extract_1").to(DEV), fx.t("extra")
+    bn1_mean_before = md["input_embedder"].bn1.running_mean.clone()
+    x = e1[:, :, :Din].clone().requires_grad_(True)
+    for m in (md["flow"], md["input_embedder"]):
+        m.zero_grad()
+    with T.step_guard(device=DEV) as guard:
+        loss, lp, _ = fa.inner_loop((e0, x, None if ex is None else ex.to(DEV)), md, cfg, eps=[e.to(DEV) for e in fx.eps()])
+        loss.backward()
+        assert not guard.overflowed()
+    assert abs(loss.item() - float(z["train/loss"])) < 2e-4 * max(1.0, abs(float(z["train/loss"])))
+    gnorm = float(z["train/grad_norm"])
+    dx_err = np.abs(x.grad.cpu().double().numpy() - z["train/d_extract_1"]).max() / max(1e-12, np.abs(z["train/d_extract_1"]).max())
+    names = json.loads(bytes(z["names_json"]).decode())["train"]
+    params = {}
+    for part in ("flow", "input_embedder"):
+        for n, p_ in md[part].named_parameters():
+            params[f"{part}/{n}"] = p_
+            params[f"{part}/{n}".replace(".augmenter.noise_dist.", ".slicer.noise_dist.")] = p_
+    worst, worst_name = 0.0, ""
+    for key in names:
+        assert params[key].grad is not None, key
+        g = params[key].grad.double().cpu().reshape(-1)
+        r = torch.from_numpy(synth.normal("gradproj/" + key, (g.numel(),), 0))
+        got = np.concatenate([[g.sum().item(), g.abs().sum().item(), (g * r).sum().item()], np.pad(g[:HEAD].numpy(), (0, max(0, HEAD - g.numel())))])
+        want = z["train/" + key]
+        err = np.abs(got - want).max() / max(want[1], 1e-4 * gnorm)          # (floor: tensors whose exact gradient is zero hold rounding noise only)
+        if err > worst:
+            worst, worst_name = err, key
+    moved = (md["input_embedder"].bn1.running_mean - bn1_mean_before).abs().max().item()
+    print(f"{case} (train mode): loss {loss.item():.6f} (ref {float(z['train/loss']):.6f}); d extract_1 rel err {dx_err:.1e}; {len(names)} parameter "
+          f"gradients (embedder + flow), worst error / L1 norm {worst:.1e} ({worst_name}); bn1 running mean moved by {moved:.2e}")
+    assert dx_err < 5e-4 and worst < 1e-3 and moved > 0
+    md["flow"].eval()
+    md["input_embedder"].eval()
