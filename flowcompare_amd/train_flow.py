@@ -261,8 +261,9 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
 
 def training_step(batch, models_dict, config, optimizer=None, eps=None, grad_clip=None):
     """One optimisation step as train.py:108-120 runs it: inner_loop -> loss.backward() -> clip_grad_norm_ -> optimizer.step().
-    The flow must be in train() mode (or the inputs require grad) so that Flow.log_prob takes the differentiable HIP path; the
-    context embedder runs its inference kernels (eval-mode BatchNorm) and receives no gradient yet (its backward is the next row).
+    The flow must be in train() mode (or the inputs require grad) so that Flow.log_prob takes the differentiable HIP path; a DGCNN
+    context embedder in train() mode is differentiated too (train_embed.py, BatchNorm batch statistics); in eval() mode -- and the
+    PAConv embedder always -- it runs its inference kernels and receives no gradient.
     Range guard: the step runs on the split-fp16 loops first and is repeated on the fp32-input loops if any operand left the fp16
     range.  Returns (loss, log_prob, bpd, grad_norm)."""
     from .model_initialization import inner_loop

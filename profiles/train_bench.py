@@ -1,5 +1,6 @@
-"""Training step timing on one MI355X: forward + backward of Flow.log_prob on the HIP training primitives at
-the bench workload's shape (C2: scenes x 4096 target + 4096 context points, spline layers), context embedder frozen in eval mode.
+"""Training step timing on one MI355X: forward + backward + Adam of the whole path on the HIP training primitives
+at the bench workload's shape (C2: scenes x 4096 target + 4096 context points, spline layers): DGCNN embedder in train() mode
+(BatchNorm batch statistics) and the flow; --frozen-embedder keeps the embedder in eval mode (inference kernels, no gradient).
 
     python profiles/train_bench.py --layers 115 --scenes 16 --steps 3        # prints one JSON line; kernel table with --profile
 """
@@ -22,6 +23,7 @@ ap.add_argument("--points", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--profile", action="store_true")
+ap.add_argument("--frozen-embedder", action="store_true")
 ap.add_argument("--budget-gb", type=float, default=-1.0, help="activation budget in GB (-1 = default: 55 %% of free HBM, 0 = checkpoint every layer)")
 a = ap.parse_args()
 dev = "cuda:0"
@@ -31,6 +33,8 @@ cfg = fa.named_config("c2_dgcnn_attn_spline", sample_size=a.points, n_flow_layer
 torch.manual_seed(0)
 md = fa.initialize_flow(cfg, device=dev, mode="test")
 md["flow"].train()
+if not a.frozen_embedder:
+    md["input_embedder"].train()
 for m in md["flow"].modules():
     if hasattr(m, "initialized"):
         m.initialized.fill_(1.0)                       # ActNorm statistics as after the first batch / a checkpoint
@@ -65,4 +69,5 @@ if a.profile:
     print(buf.value.decode())
 ms = 1e3 * sum(times) / len(times)
 print(json.dumps({"metric": "training step (forward + backward + Adam), points/s", "value": B * N / (ms / 1e3), "ms_per_step": ms, "layers": a.layers,
-                  "scenes": B, "points": N, "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30, "embedder": "frozen (eval)"}))
+                  "scenes": B, "points": N, "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30,
+                  "embedder": "frozen (eval)" if a.frozen_embedder else "trained (BatchNorm batch statistics)"}))
