@@ -360,9 +360,9 @@ class _DGCNNBase(nn.Module):
         return self._handle
 
     def forward(self, x):
-        """x [B,M,6] -> [B,M,E] (per-point) or [B,E] (global).  In train() mode under autograd: the differentiable HIP path with
-        BatchNorm batch statistics (train_embed.py); otherwise the fused inference engine (eval-mode BatchNorm)."""
-        if self.training and torch.is_grad_enabled():
+        """x [B,M,6] -> [B,M,E] (per-point) or [B,E] (global).  In train() mode: the differentiable HIP path with BatchNorm batch
+        statistics (train_embed.py); in eval() mode the fused inference engine (running statistics)."""
+        if self.training:                                  # (also under no_grad: train-mode BatchNorm normalises with batch statistics)
             from . import train_embed
             return train_embed.dgcnn_embed(self, x)
         return self._engine().embed(x)

@@ -436,3 +436,60 @@ def test_full_training_step_matches_reference_train_mode_gradients(case):
     assert dx_err < 5e-4 and worst < 1e-3 and moved > 0
     md["flow"].eval()
     md["input_embedder"].eval()
+
+
+# ---------------------------------------------------------------- two ranks on the card: sharded step + bucketed gradient all-reduce
+def _sharded_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flowcompare_amd import shard
+        fx = Fixture("e2e_tiny_affine")                       # 3 scenes: uneven split 2 + 1
+        cfg, md = _build(fx)
+        md["flow"].train()                                    # embedder stays in eval(): BatchNorm batch statistics would be per shard
+        reducer = shard.GradientReducer(md["flow"].parameters(), bucket_bytes=64 << 10)
+        batch = tuple(None if t is None else t.to(DEV) for t in (fx.t("extract_0"), fx.t("extract_1"), fx.t("extra")))
+        loss, lp, bpd, norm = shard.sharded_training_step(batch, md, cfg, reducer, optimizer=None, eps=[e.to(DEV) for e in fx.eps()], grad_clip=0)
+        grads = {n: p.grad.detach().cpu().double().numpy() for n, p in md["flow"].named_parameters() if p.grad is not None}
+        q.put((rank, float(loss), lp.shape[0], grads))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sharded_training_step_matches_reference_full_batch_gradients():
+    """Two processes on the one card (gloo): each differentiates its scenes (2 + 1) through the HIP training path, the bucketed SUM
+    all-reduce runs from the backward hooks, and both ranks end with the flow gradients the reference's loss.backward() produced for
+    the FULL batch (tests/golden/grad_tiny_affine.npz, eval record: the embedder is frozen here)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    world = 2
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=500) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    z = np.load(os.path.join(GOLDEN, "grad_tiny_affine.npz"))
+    gnorm = float(z["eval/grad_norm"])
+    assert [r[2] for r in res] == [2, 1]
+    worst = 0.0
+    for rank, loss, _, grads in res:
+        assert abs(loss - float(z["eval/loss"])) < 2e-4 * abs(float(z["eval/loss"]))
+        for key in json.loads(bytes(z["names_json"]).decode())["eval"]:
+            if not key.startswith("flow/"):
+                continue
+            g = torch.from_numpy(grads[key.split("/", 1)[1]]).reshape(-1)
+            r = torch.from_numpy(synth.normal("gradproj/" + key, (g.numel(),), 0))
+            got = np.array([g.sum().item(), g.abs().sum().item(), (g * r).sum().item()])
+            want = z["eval/" + key]
+            worst = max(worst, np.abs(got - want[:3]).max() / max(want[1], 1e-4 * gnorm))
+    for k in res[0][3]:
+        assert np.array_equal(res[0][3][k], res[1][3][k])      # identical reduced gradients on both ranks
+    print(f"two ranks, 2 + 1 scenes: worst flow-gradient error / L1 norm vs the reference's full-batch backward {worst:.1e}")
+    assert worst < 1e-4
