@@ -13,8 +13,8 @@ What runs where
 
 Covered: AugmentAttentionPreconditioner or IdentityTransform; PreConditionApplier with the attention or the global-context
 pre-conditioner; CIFblock (augment / affine_cif / ActNorm / Slice around the coupling); RationalQuadraticSplineCoupling or
-AffineCoupling; ActNormBijectionCloud (initialised); LinearLU; extra context.  Not yet: ExponentialCoupling and the alternative
-permuters (they raise NotImplementedError).
+AffineCoupling; ActNormBijectionCloud incl. its first-batch init; LinearLU, random_permute, FullCombiner, ExponentialCombiner; extra
+context.  Not yet: ExponentialCoupling (raises NotImplementedError).
 """
 import math
 
@@ -46,16 +46,30 @@ def _kv(pre, ctx_panel, E, ctx_rows):
     return (T.linear_act([ctx_panel], [E], w[:inner], None, ctx_rows), T.linear_act([ctx_panel], [E], w[inner:], None, ctx_rows))
 
 
-def _lu_weight(perm):
-    """models/permuters.py:148-162: W = L U with unit-lower L and diag(U) = softplus(u) + eps; returns (W, sum log diag)."""
-    D = perm.num_features
-    dev = perm.lower_entries.device
-    diag = torch.nn.functional.softplus(perm.unconstrained_upper_diag) + perm.eps
-    il = torch.tril_indices(D, D, -1, device=dev)
-    iu = torch.triu_indices(D, D, 1, device=dev)
-    L = torch.eye(D, device=dev, dtype=diag.dtype).index_put((il[0], il[1]), perm.lower_entries)
-    U = torch.diag(diag).index_put((iu[0], iu[1]), perm.upper_entries)
-    return L @ U, torch.log(diag).sum()
+def _perm_weight(perm, cfg):
+    """The permuter between layers as a matrix W (z = W x) and its log|det|, built in parameter space (torch autograd carries dW back):
+    LinearLU (models/permuters.py:148-169: W = L U, unit-lower L, diag(U) = softplus(u) + eps), Permuter / random_permute (:55-70: a
+    fixed permutation), FullCombiner (:15-30: W = w, slogdet), ExponentialCombiner (:34-53: W = expm(rescale tanh(scale w + shift) +
+    reshift + 1e-8), log|det| = trace; torch.matrix_exp stands in for the reference's truncated series, which is converged to eps_expm)."""
+    dev = next(perm.parameters(), None)
+    if isinstance(perm, M.LinearLU):
+        D = perm.num_features
+        dev = perm.lower_entries.device
+        diag = torch.nn.functional.softplus(perm.unconstrained_upper_diag) + perm.eps
+        il = torch.tril_indices(D, D, -1, device=dev)
+        iu = torch.triu_indices(D, D, 1, device=dev)
+        L = torch.eye(D, device=dev, dtype=diag.dtype).index_put((il[0], il[1]), perm.lower_entries)
+        U = torch.diag(diag).index_put((iu[0], iu[1]), perm.upper_entries)
+        return L @ U, torch.log(diag).sum()
+    if isinstance(perm, M.Permuter):
+        D = perm.permutation.numel()
+        return torch.eye(D, device=perm.permutation.device)[perm.permutation.long()], torch.zeros((), device=perm.permutation.device)
+    if isinstance(perm, M.FullCombiner):
+        return perm.w, torch.linalg.slogdet(perm.w)[1]
+    if isinstance(perm, M.ExponentialCombiner):
+        wm = perm.rescale * torch.tanh(perm.scale * perm.w + perm.shift) + perm.reshift + 1e-8
+        return torch.matrix_exp(wm), wm.diagonal().sum()
+    raise NotImplementedError(f"training path: permuter {type(perm).__name__}")
 
 
 def _actnorm_data_init(an, parts, rows):
@@ -185,7 +199,7 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
                 W, b = torch.diag(g), -an.shift.reshape(-1) * g
                 logp = logp - an.log_scale.sum()
             if perm is not None:
-                Wlu, logdet = _lu_weight(perm)
+                Wlu, logdet = _perm_weight(perm, cfg)
                 W, b = (Wlu, None) if W is None else (Wlu @ W, Wlu @ b)
                 logp = logp + logdet
             if W is not None:
@@ -225,11 +239,11 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
         if i < len(transforms) and isinstance(transforms[i], M.ActNormBijectionCloud):
             an = transforms[i]
             i += 1
-        if i < len(transforms) and isinstance(transforms[i], M.LinearLU):
+        if i < len(transforms) and isinstance(transforms[i], (M.LinearLU, M.Permuter, M.FullCombiner, M.ExponentialCombiner)):
             perm = transforms[i]
             i += 1
         elif i < len(transforms) and not isinstance(transforms[i], (M.PreConditionApplier, M.CIFblock)):
-            raise NotImplementedError(f"training path: permuter {type(transforms[i]).__name__} is not built yet")
+            raise NotImplementedError(f"training path: transform {type(transforms[i]).__name__} between layers")
         # un-initialised ActNorm layers take their statistics from this batch, in training mode only (act_norm.py:38-39)
         init_an = an is not None and float(an.initialized.item()) == 0.0
         init_cif = isinstance(blk, M.CIFblock) and float(blk.act_norm.initialized.item()) == 0.0

@@ -236,7 +236,7 @@ def _train_step(fx, cfg, md, fp16=True):
     return loss, lp, x, ctx
 
 
-@pytest.mark.parametrize("case", ["tiny_spline_relu", "tiny_affine", "spline_L2", "tiny_cif", "tiny_global_extra"])
+@pytest.mark.parametrize("case", ["tiny_spline_relu", "tiny_affine", "spline_L2", "tiny_cif", "tiny_global_extra", "tiny_random_permute"])
 def test_flow_backward_matches_reference_gradients(case):
     """loss.backward() through the HIP training path against the gradients the REFERENCE produced for the same weights, inputs and
     noise (tests/golden/grad_*.npz, eval mode): every flow parameter through sum / L1 / random projection / first entries, and
@@ -493,3 +493,32 @@ def test_two_rank_sharded_training_step_matches_reference_full_batch_gradients()
         assert np.array_equal(res[0][3][k], res[1][3][k])      # identical reduced gradients on both ranks
     print(f"two ranks, 2 + 1 scenes: worst flow-gradient error / L1 norm vs the reference's full-batch backward {worst:.1e}")
     assert worst < 1e-4
+
+
+@pytest.mark.parametrize("name", ["e2e_tiny_FullCombiner", "e2e_tiny_ExponentialCombiner"])
+def test_flow_backward_with_dense_combiners_matches_oracle_autograd(name):
+    """FullCombiner / ExponentialCombiner between the layers (models/permuters.py:15-53): their weights are built in parameter space and
+    applied by the training Linear; gradients (incl. w and the tanh-rescale scalars) against fp64 autograd through the pinned oracle."""
+    fx = Fixture(name)
+    cfg, md = _build(fx)
+    loss, lp, x, ctx = _train_step(fx, cfg, md)
+    c = fx.derived_cfg()
+    sd_f, _ = fx.state_dicts(torch.float64)
+    for v in sd_f.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    e1 = fx.t("extract_1", torch.float64)[:, :, :c["input_dim"]].requires_grad_(True)
+    ex = fx.t("extra", torch.float64)
+    ex = None if ex is None else ex[:, None, :].expand(-1, e1.shape[1], -1)
+    lp_o = O.flow_log_prob(c, sd_f, e1, ctx.detach().cpu().double(), ex, fx.eps(torch.float64))
+    (-lp_o.mean()).backward()
+    gn = sum(float((v.grad ** 2).sum()) for v in sd_f.values() if v.is_floating_point() and v.grad is not None) ** 0.5
+    worst, worst_name = 0.0, ""
+    for n, p in md["flow"].named_parameters():
+        if sd_f[n].grad is None:
+            continue
+        e = (p.grad.double().cpu() - sd_f[n].grad).abs().sum().item() / max(sd_f[n].grad.abs().sum().item(), 1e-4 * gn)
+        if e > worst:
+            worst, worst_name = e, n
+    print(f"{name}: loss diff {abs(loss.item() + lp_o.mean().item()):.1e} dx {_rel(x.grad, e1.grad):.1e}; worst parameter gradient L1 error {worst:.1e} ({worst_name})")
+    assert abs(loss.item() + lp_o.mean().item()) < 2e-4 * max(1.0, abs(lp_o.mean().item())) and _rel(x.grad, e1.grad) < 5e-4 and worst < 1e-3
