@@ -211,6 +211,7 @@ struct Attn16Params {
     const float* q_sumsq; int q_slots; size_t q_pitch; float q_inv_width; const float* q_bias;
     int kv_pitch;                   // row pitch of the k16 / v16 images in 16-byte chunks (DH / 4 for the packed images)
     int c16;                        // 1: rows are slices of a GEMM's limb-image output ([16 columns: hi 16 | lo' 16] tiles, GemmEpi::C16)
+    float* lse = nullptr;           // optional [B * n_stride]: natural-log sum-exp of every query's scaled scores (training: the backward reuses it)
 };
 
 // fp32 K / V columns of the projected context -> limb row images; raises *ovf on |x| >= 65504.
@@ -429,6 +430,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #undef FC_GLOAD
 #undef FC_LSTORE
 
+    if (p.lse && lane < 32 && q0 + lane < p.N)                   // scores are in the log2 domain (qscale carries log2 e)
+        p.lse[(size_t)b * p.n_stride + q0 + lane] = (m_run + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f;
     // ---- normalise and store: O rows are queries (r&3)+8(r>>2)+4h of this wave, columns d = 32*dt + lane&31
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -478,7 +481,7 @@ static void launch_attn_dh(const AttnParams& p, int B, hipStream_t s) {
 static void launch_attention_scaled(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                                     int B, int N, int n_stride_rows, int M, int m_stride_rows, int dh_pad, float qscale, void* limb_ws,
                                     hipStream_t s, const unsigned short* k_c16 = nullptr, const unsigned short* v_c16 = nullptr, int c16_pitch = 0,
-                                    const AttnLnq* lnq = nullptr) {
+                                    const AttnLnq* lnq = nullptr, float* lse = nullptr, bool* lse_written = nullptr) {
     if (B <= 0 || N <= 0 || M <= 0) throw Error(FC_ERR_INVALID, "attention: empty problem");
     if (k_c16) {
         // K / V arrive as slices of the projection GEMM's limb-image output: no fp32 K / V, no conversion pass
@@ -505,6 +508,8 @@ static void launch_attention_scaled(const float* q, int ldq, const float* k, int
             FC_HIP(hipGetLastError());
         }
         Attn16Params p{q, ldq, k16, v16, out, ldo, N, n_stride_rows, M, m_stride_rows, qscale, flag, nullptr, 0, 0, 0.f, nullptr, dh_pad / 4, 0};
+        p.lse = lse;
+        if (lse_written) *lse_written = lse != nullptr;
         if (dh_pad == 32) launch_attn16_dh<32>(p, B, s); else launch_attn16_dh<64>(p, B, s);
         return;
     }
@@ -534,9 +539,13 @@ void launch_attention_c16(const float* q, int ldq, const unsigned short* kv_c16,
 }
 
 // training path (train_attention.hip): strided q / k / v (columns of wider panels), explicit softmax scale
-void launch_attention_scaled_op(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int N, int M,
-                                int dh_pad, float scale, void* limb_ws, hipStream_t s) {
-    launch_attention_scaled(q, ldq, k, ldk, v, ldv, out, ldo, B, N, N, M, M, dh_pad, scale * 1.4426950408889634f, limb_ws, s);
+// lse (optional, [B * N]): filled by the split-fp16 kernel only; the return value says whether it was
+bool launch_attention_scaled_op(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int N, int M,
+                                int dh_pad, float scale, void* limb_ws, hipStream_t s, float* lse) {
+    bool written = false;
+    launch_attention_scaled(q, ldq, k, ldk, v, ldv, out, ldo, B, N, N, M, M, dh_pad, scale * 1.4426950408889634f, limb_ws, s, nullptr, nullptr, 0,
+                            nullptr, lse, &written);
+    return written;
 }
 
 void launch_attention_op(const float* q, const float* k, const float* v, float* out, int B, int N, int M, int dh_pad, float scale,

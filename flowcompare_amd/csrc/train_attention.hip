@@ -31,6 +31,7 @@ struct AttnBwdParams {
     float* lse; float* dvec;       // [B * N] each
     int N, M;
     float scale;
+    int have_lse;                  // lse was written by the forward kernel: the dq kernel skips its own log-sum-exp pass
 };
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -280,9 +281,9 @@ __global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int
     const int ntiles = (p.M + 31) / 32;
     const int a_off = li * A16_PITCH + 16 * h;                        // row li, 8 halfs at head dim 8 h of a 16-dim step
     const int tr_off = (4 * h + ((lane & 15) >> 2)) * A16_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    // ---- pass A: log-sum-exp per query
+    // ---- pass A: log-sum-exp per query (skipped when the forward kernel left it in p.lse)
     float m = -INFINITY, l = 0.f;
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < (p.have_lse ? 0 : ntiles); ++t) {
         __syncthreads();
         amax = fmaxf(amax, stage_limbs(kb, p.ldk, t * 32, p.M, sK, tid));
         __syncthreads();
@@ -310,8 +311,8 @@ __global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int
         l = l * expf(m - mn) + ts;
         m = mn;
     }
-    const float lse = m + logf(l);
-    if (qok && h == 0) { p.lse[grow] = lse; p.dvec[grow] = dsum; }
+    const float lse = p.have_lse ? p.lse[grow] : m + logf(l);
+    if (qok && h == 0) { if (!p.have_lse) p.lse[grow] = lse; p.dvec[grow] = dsum; }
     // ---- pass B: dQ^T[d][query] += K^T dS^T
     f32x16 qm[2], qc[2];
 #pragma unroll
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int
         for (int r = 0; r < 16; ++r) { qm[i][r] = 0.f; qc[i][r] = 0.f; }
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
-        stage_limbs(kb, p.ldk, t * 32, p.M, sK, tid);
+        amax = fmaxf(amax, stage_limbs(kb, p.ldk, t * 32, p.M, sK, tid));
         amax = fmaxf(amax, stage_limbs(vb, p.ldv, t * 32, p.M, sV, tid));
         __syncthreads();
         f32x16 sm, sc, pm, pc;
@@ -479,8 +480,8 @@ static void launch_attn_bwd(const AttnBwdParams& p, int B, hipStream_t s) {
     FC_HIP(hipGetLastError());
 }
 
-void launch_attention_scaled_op(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int N, int M,
-                                int dh_pad, float scale, void* limb_ws, hipStream_t s);      // attention.hip
+bool launch_attention_scaled_op(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo, int B, int N, int M,
+                                int dh_pad, float scale, void* limb_ws, hipStream_t s, float* lse);      // attention.hip
 
 }  // namespace fc
 
@@ -505,25 +506,29 @@ size_t fc_train_attention_ws_bytes(int32_t B, int32_t N, int32_t M, int32_t D) {
 }
 
 int fc_train_attention_fwd_f32(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, float* out, int32_t ldo,
-                               int32_t B, int32_t N, int32_t M, int32_t D, float scale, void* ws, size_t ws_bytes, int32_t* ovf, void* stream) {
+                               int32_t B, int32_t N, int32_t M, int32_t D, float scale, void* ws, size_t ws_bytes, float* stats, int32_t* stats_valid,
+                               int32_t* ovf, void* stream) {
     FC_API_BEGIN
     if (B < 1 || N < 1 || M < 1 || (D != 32 && D != 64)) throw Error(FC_ERR_UNSUPPORTED, "fc_train_attention_fwd_f32: head dim (padded) must be 32 or 64");
     check_mat(q, ldq, D, "q"); check_mat(k, ldk, D, "k"); check_mat(v, ldv, D, "v"); check_mat(out, ldo, D, "out");
     const bool f16 = ovf && ws && ws_bytes >= fc_train_attention_ws_bytes(B, N, M, D) && !((uintptr_t)ws & 15);
     Fp16FlagScope scope(f16 ? (int*)ovf : nullptr);
-    launch_attention_scaled_op(q, ldq, k, ldk, v, ldv, out, ldo, B, N, M, D, scale, f16 ? ws : nullptr, (hipStream_t)stream);
+    const bool wrote = launch_attention_scaled_op(q, ldq, k, ldk, v, ldv, out, ldo, B, N, M, D, scale, f16 ? ws : nullptr, (hipStream_t)stream,
+                                                  (f16 && D == 64) ? stats : nullptr);
+    if (stats_valid) *stats_valid = wrote ? 1 : 0;
     FC_API_END
 }
 
 int fc_train_attention_bwd_f32(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* out, int32_t ldo,
                                const float* dout, int32_t lddo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv, int32_t lddv,
-                               float* stats, int32_t B, int32_t N, int32_t M, int32_t D, float scale, int32_t* ovf, void* stream) {
+                               float* stats, int32_t stats_valid, int32_t B, int32_t N, int32_t M, int32_t D, float scale, int32_t* ovf, void* stream) {
     FC_API_BEGIN
     if (B < 1 || N < 1 || M < 1 || (D != 32 && D != 64)) throw Error(FC_ERR_UNSUPPORTED, "fc_train_attention_bwd_f32: head dim (padded) must be 32 or 64");
     check_mat(q, ldq, D, "q"); check_mat(k, ldk, D, "k"); check_mat(v, ldv, D, "v"); check_mat(out, ldo, D, "out"); check_mat(dout, lddo, D, "dout");
     check_mat(dq, lddq, D, "dq"); check_mat(dk, lddk, D, "dk"); check_mat(dv, lddv, D, "dv");
     if (!stats) throw Error(FC_ERR_INVALID, "fc_train_attention_bwd_f32: stats scratch [2 * B * N] is required");
-    AttnBwdParams p{q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, dq, lddq, dk, lddk, dv, lddv, stats, stats + (size_t)B * N, N, M, scale};
+    AttnBwdParams p{q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, dq, lddq, dk, lddk, dv, lddv, stats, stats + (size_t)B * N, N, M, scale, 0};
+    p.have_lse = (stats_valid && D == 64 && ovf && g_train_attn16) ? 1 : 0;
     if (D == 64 && ovf && g_train_attn16) launch_attn_bwd16(p, B, (int*)ovf, (hipStream_t)stream);
     else if (D == 32) launch_attn_bwd<32>(p, B, (hipStream_t)stream);
     else launch_attn_bwd<64>(p, B, (hipStream_t)stream);

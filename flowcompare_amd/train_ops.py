@@ -235,25 +235,28 @@ class AttentionFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             nb = L.fc_train_attention_ws_bytes(B, N, M, D)
             ws = _ws(nb, dev) if _Step.flag is not None else None
+            stats = torch.empty(2 * B * N, dtype=torch.float32, device=dev)
+            valid = ctypes.c_int32(0)
             engine._check(L.fc_train_attention_fwd_f32(engine._ptr(q), D, engine._ptr(k), D, engine._ptr(v), D, engine._ptr(out), D, B, N, M, D,
-                                                       ctypes.c_float(scale), engine._ptr(ws), ctypes.c_size_t(nb), _flag_ptr(), engine._stream()))
-        ctx.save_for_backward(q, k, v, out)
-        ctx.meta = (B, N, M, D, scale)
+                                                       ctypes.c_float(scale), engine._ptr(ws), ctypes.c_size_t(nb), engine._ptr(stats),
+                                                       ctypes.byref(valid), _flag_ptr(), engine._stream()))
+        ctx.save_for_backward(q, k, v, out, stats)
+        ctx.meta = (B, N, M, D, scale, int(valid.value))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         L = engine.lib()
-        q, k, v, out = ctx.saved_tensors
-        B, N, M, D, scale = ctx.meta
+        q, k, v, out, stats = ctx.saved_tensors
+        B, N, M, D, scale, stats_valid = ctx.meta
         dout = dout.contiguous()
         dq = _panel_out(q.shape[0], D, B * N, q.device)
         dk, dv = _panel_out(k.shape[0], D, B * M, q.device), _panel_out(k.shape[0], D, B * M, q.device)
-        stats = torch.empty(2 * B * N, dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
             engine._check(L.fc_train_attention_bwd_f32(engine._ptr(q), D, engine._ptr(k), D, engine._ptr(v), D, engine._ptr(out), D,
                                                        engine._ptr(dout), D, engine._ptr(dq), D, engine._ptr(dk), D, engine._ptr(dv), D,
-                                                       engine._ptr(stats), B, N, M, D, ctypes.c_float(scale), _flag_ptr(), engine._stream()))
+                                                       engine._ptr(stats), stats_valid if _Step.flag is not None else 0, B, N, M, D,
+                                                       ctypes.c_float(scale), _flag_ptr(), engine._stream()))
         return dq, dk, dv, None, None, None, None
 
 

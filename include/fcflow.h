@@ -225,13 +225,16 @@ int fc_train_act_bwd_f32(const float* dy, const float* u, float* du, int32_t row
 /* Cross-attention core out = softmax(q k^T scale) v per scene (models/perceiver.py:106-113) on row-major matrices with pitches
  * (q, out, dout, dq: [B*N, ld]; k, v, dk, dv: [B*M, ld]; D = padded head dim, 32 or 64) and its backward, which recomputes the
  * scores tile by tile (nothing of [N, M] is stored).  fwd: ws (fc_train_attention_ws_bytes) + ovf select the split-fp16 kernel.
- * bwd: stats = device scratch of 2*B*N floats (log-sum-exp and dO.O per query); ovf selects the split-fp16 kernels (D = 64). */
+ * stats = device buffer of 2*B*N floats (log-sum-exp and dO.O per query): the split-fp16 forward leaves the log-sum-exp in its first
+ * half and sets *stats_valid (host int), which the backward takes back to skip its own pass; ovf selects the split-fp16 kernels (D = 64). */
 size_t fc_train_attention_ws_bytes(int32_t B, int32_t N, int32_t M, int32_t D);
 int fc_train_attention_fwd_f32(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, float* out, int32_t ldo,
-                               int32_t B, int32_t N, int32_t M, int32_t D, float scale, void* ws, size_t ws_bytes, int32_t* ovf, void* stream);
+                               int32_t B, int32_t N, int32_t M, int32_t D, float scale, void* ws, size_t ws_bytes, float* stats, int32_t* stats_valid,
+                               int32_t* ovf, void* stream);
 int fc_train_attention_bwd_f32(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* out,
                                int32_t ldo, const float* dout, int32_t lddo, float* dq, int32_t lddq, float* dk, int32_t lddk, float* dv,
-                               int32_t lddv, float* stats, int32_t B, int32_t N, int32_t M, int32_t D, float scale, int32_t* ovf, void* stream);
+                               int32_t lddv, float* stats, int32_t stats_valid, int32_t B, int32_t N, int32_t M, int32_t D, float scale, int32_t* ovf,
+                               void* stream);
 
 /* Rational-quadratic spline coupling element in the reference's parameter layout (models/spline_coupling.py:187-210: the coupling
  * MLP's output row is [d2][K width | K height | K+1 derivative logits]), forward (y2, ldj[row] = sum over dims of log|dy/dx|) and
