@@ -522,3 +522,55 @@ def test_flow_backward_with_dense_combiners_matches_oracle_autograd(name):
             worst, worst_name = e, n
     print(f"{name}: loss diff {abs(loss.item() + lp_o.mean().item()):.1e} dx {_rel(x.grad, e1.grad):.1e}; worst parameter gradient L1 error {worst:.1e} ({worst_name})")
     assert abs(loss.item() + lp_o.mean().item()) < 2e-4 * max(1.0, abs(lp_o.mean().item())) and _rel(x.grad, e1.grad) < 5e-4 and worst < 1e-3
+
+
+def test_five_adam_steps_follow_the_oracle_trajectory():
+    """train.py's loop body (inner_loop -> backward -> clip_grad_norm_ -> Adam) for five steps on the HIP path, embedder and flow in
+    train mode, against the same five steps of the pinned oracle under fp64 autograd with the same optimiser: the loss trajectory
+    and the parameters after the last step."""
+    fx = Fixture("e2e_tiny_affine")
+    cfg, md = _build(fx)
+    md["flow"].train()
+    md["input_embedder"].train()
+    cfg = dict(cfg)
+    cfg["grad_clip_val"] = 5.0
+    batch = tuple(None if t is None else t.to(DEV) for t in (fx.t("extract_0"), fx.t("extract_1"), fx.t("extra")))
+    eps = [e.to(DEV) for e in fx.eps()]
+    opt = torch.optim.Adam(md["parameters"], lr=2e-3)
+    # the oracle side: same weights as leaf tensors, same Adam, same clipping
+    c = fx.derived_cfg()
+    sd_f, sd_e = fx.state_dicts(torch.float64)
+    import re
+    opt_leaves = []                                  # exactly the tensors that are nn.Parameters in the module mirror (bn{i} = conv{i}.1)
+    for part, sd in (("flow", sd_f), ("input_embedder", sd_e)):
+        for n, p_ in md[part].named_parameters():
+            alias = re.sub(r"^bn(\d)\.", r"conv\1.1.", n)
+            opt_leaves.append(sd[alias].requires_grad_(True))
+    opt_o = torch.optim.Adam(opt_leaves, lr=2e-3)
+    b64 = (fx.t("extract_0", torch.float64), fx.t("extract_1", torch.float64), fx.t("extra", torch.float64))
+    losses_h, losses_o = [], []
+    for step in range(5):
+        loss, _, _, _ = TF.training_step(batch, md, cfg, optimizer=opt, eps=eps)
+        losses_h.append(loss.item())
+        opt_o.zero_grad(set_to_none=True)
+        with O.train_mode():
+            lo, _, _ = O.inner_loop(c, sd_f, sd_e, b64, fx.eps(torch.float64))
+        lo.backward()
+        torch.nn.utils.clip_grad_norm_([v for v in opt_leaves if v.grad is not None], max_norm=5.0)
+        opt_o.step()
+        losses_o.append(lo.item())
+    worst, diffs = 0.0, []
+    for part, sd in (("flow", sd_f), ("input_embedder", sd_e)):
+        for n, p_ in md[part].named_parameters():
+            alias = re.sub(r"^bn(\d)\.", r"conv\1.1.", n)
+            d = (p_.detach().cpu().double() - sd[alias].detach()).abs().max().item()
+            diffs.append((d, part + "/" + n))
+            worst = max(worst, d)
+    print("largest parameter differences:", [(f"{d:.1e}", n) for d, n in sorted(diffs, reverse=True)[:3]])
+    print("loss trajectory HIP   : " + " ".join(f"{v:.5f}" for v in losses_h))
+    print("loss trajectory oracle: " + " ".join(f"{v:.5f}" for v in losses_o) + f"   max parameter difference after 5 steps {worst:.1e}")
+    assert losses_h[-1] < losses_h[0]
+    assert max(abs(a - b) for a, b in zip(losses_h, losses_o)) < 1e-5 * abs(losses_o[0])
+    assert worst < 1e-3
+    md["flow"].eval()
+    md["input_embedder"].eval()
