@@ -345,6 +345,143 @@ __global__ __launch_bounds__(256) void base_train_bwd_kernel(const float* __rest
     for (int j = threadIdx.x; j < width_pad; j += 256) dx[row * lddx + j] = j < width ? -x[row * ldx + j] * gr : 0.f;
 }
 
+
+// ---------------------------------------------------------------- ExponentialCoupling (models/exponential_coupling.py:44-58, utils.py:294-327)
+// o = [d2 x d2 raw matrix | d2 shift] per point, W = rescale tanh(scale raw + shift) + reshift + 1e-8, y2 = expm(W) x2 + b, ldj = tr W.
+// Forward = the inference kernel's arithmetic (misc.hip): A = W 2^-s with |A|_inf <= 1/2, the 12-term Taylor ACTION u = sum_k A^k v / k!
+// applied 2^s times.  Backward = exact reverse mode through that recurrence: the intermediate vectors v_rep are kept, each action is
+// replayed for its terms t_k and differentiated with mu_12 = lambda, mu_{k-1} = lambda + A^T mu_k / k, dA += mu_k t_{k-1}^T / k.
+// One thread per point with per-thread arrays (scratch): the layer only exists for small d2, like in the reference.
+constexpr int EX_D = 16, EX_REP = 64;
+__device__ __forceinline__ int expm_prepare(const float* pr, int d2, const float* scal4, float* w, float& tr) {
+    const float sc = scal4[0], sh = scal4[1], rs = scal4[2], rsh = scal4[3];
+    float nrm = 0.f;
+    tr = 0.f;
+    for (int i = 0; i < d2; ++i) {
+        float rsum = 0.f;
+        for (int j = 0; j < d2; ++j) {
+            const float wij = rs * tanhf(sc * pr[i * d2 + j] + sh) + rsh + 1e-8f;
+            if (i == j) tr += wij;
+            w[i * EX_D + j] = wij;
+            rsum += fabsf(wij);
+        }
+        nrm = fmaxf(nrm, rsum);
+    }
+    int s = 0;
+    while (nrm > 0.5f && s < 6) { nrm *= 0.5f; ++s; }          // 2^6 = EX_REP stored states at most
+    return s;
+}
+__global__ void expm_train_fwd_kernel(const float* __restrict__ x2, int ldx, const float* __restrict__ o, int ldo, const float* __restrict__ scal4,
+                                      float* __restrict__ y2, int ldy, float* __restrict__ ldj, int rows, int d2, int d2_pad, int* __restrict__ status) {
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= rows) return;
+    const float* pr = o + (size_t)row * ldo;
+    float w[EX_D * EX_D], v[EX_D], term[EX_D], acc[EX_D];
+    float tr;
+    const int s = expm_prepare(pr, d2, scal4, w, tr);
+    {
+        float nrm = 0.f;
+        for (int i = 0; i < d2; ++i) { float r = 0.f; for (int j = 0; j < d2; ++j) r += fabsf(w[i * EX_D + j]); nrm = fmaxf(nrm, r); }
+        if (ldexpf(nrm, -s) > 0.5f) atomicOr(status, 1);         // |W| too large for the stored-state budget: reported by the host
+    }
+    const float f = ldexpf(1.0f, -s);
+    for (int i = 0; i < d2; ++i) v[i] = x2[(size_t)row * ldx + i];
+    for (int rep = 0; rep < (1 << s); ++rep) {
+        for (int i = 0; i < d2; ++i) { acc[i] = v[i]; term[i] = v[i]; }
+        for (int k = 1; k <= 12; ++k) {
+            float nt[EX_D];
+            const float fk = f / (float)k;
+            for (int i = 0; i < d2; ++i) {
+                float a = 0.f;
+                for (int j = 0; j < d2; ++j) a = fmaf(w[i * EX_D + j], term[j], a);
+                nt[i] = a * fk;
+            }
+            for (int i = 0; i < d2; ++i) { term[i] = nt[i]; acc[i] += nt[i]; }
+        }
+        for (int i = 0; i < d2; ++i) v[i] = acc[i];
+    }
+    for (int i = 0; i < d2_pad; ++i) y2[(size_t)row * ldy + i] = i < d2 ? v[i] + pr[d2 * d2 + i] : 0.f;
+    ldj[row] = tr;
+}
+
+// do [rows, ldo] gets d raw matrix | d shift (pads zero); dscal [rows, 4] the per-point parts of d scale, d shift, d rescale, d reshift
+__global__ void expm_train_bwd_kernel(const float* __restrict__ x2, int ldx, const float* __restrict__ o, int ldo, const float* __restrict__ scal4,
+                                      const float* __restrict__ dy2, int lddy, const float* __restrict__ dldj, float* __restrict__ dx2, int lddx,
+                                      float* __restrict__ dout, int lddo, float* __restrict__ dscal, int rows, int d2, int d2_pad, int no_pad) {
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= rows) return;
+    const float* pr = o + (size_t)row * ldo;
+    float w[EX_D * EX_D], dA[EX_D * EX_D], V[EX_REP + 1][EX_D], T[13][EX_D], lam[EX_D], mu[EX_D];
+    float tr;
+    const int s = expm_prepare(pr, d2, scal4, w, tr);
+    const float f = ldexpf(1.0f, -s);
+    const int R = 1 << s;
+    for (int i = 0; i < d2; ++i) V[0][i] = x2[(size_t)row * ldx + i];
+    for (int rep = 0; rep < R; ++rep) {                           // forward again, keeping every state
+        float term[EX_D], acc[EX_D];
+        for (int i = 0; i < d2; ++i) { acc[i] = V[rep][i]; term[i] = V[rep][i]; }
+        for (int k = 1; k <= 12; ++k) {
+            float nt[EX_D];
+            const float fk = f / (float)k;
+            for (int i = 0; i < d2; ++i) {
+                float a = 0.f;
+                for (int j = 0; j < d2; ++j) a = fmaf(w[i * EX_D + j], term[j], a);
+                nt[i] = a * fk;
+            }
+            for (int i = 0; i < d2; ++i) { term[i] = nt[i]; acc[i] += nt[i]; }
+        }
+        for (int i = 0; i < d2; ++i) V[rep + 1][i] = acc[i];
+    }
+    for (int i = 0; i < d2 * EX_D; ++i) dA[i] = 0.f;
+    for (int i = 0; i < d2; ++i) lam[i] = dy2[(size_t)row * lddy + i];
+    for (int rep = R - 1; rep >= 0; --rep) {
+        // terms of this action: t_0 = v, t_k = (f / k) W t_{k-1}
+        for (int i = 0; i < d2; ++i) T[0][i] = V[rep][i];
+        for (int k = 1; k <= 12; ++k) {
+            const float fk = f / (float)k;
+            for (int i = 0; i < d2; ++i) {
+                float a = 0.f;
+                for (int j = 0; j < d2; ++j) a = fmaf(w[i * EX_D + j], T[k - 1][j], a);
+                T[k][i] = a * fk;
+            }
+        }
+        for (int i = 0; i < d2; ++i) mu[i] = lam[i];              // mu_12
+        for (int k = 12; k >= 1; --k) {
+            const float fk = f / (float)k;
+            // d W += (f / k) mu_k t_{k-1}^T ; mu_{k-1} = lambda + (f / k) W^T mu_k
+            float nm[EX_D];
+            for (int j = 0; j < d2; ++j) nm[j] = lam[j];
+            for (int i = 0; i < d2; ++i) {
+                const float mi = mu[i] * fk;
+                for (int j = 0; j < d2; ++j) {
+                    dA[i * EX_D + j] = fmaf(mi, T[k - 1][j], dA[i * EX_D + j]);
+                    nm[j] = fmaf(w[i * EX_D + j], mi, nm[j]);
+                }
+            }
+            for (int j = 0; j < d2; ++j) mu[j] = nm[j];
+        }
+        for (int i = 0; i < d2; ++i) lam[i] = mu[i];              // adjoint of this action's input
+    }
+    for (int i = 0; i < d2_pad; ++i) dx2[(size_t)row * lddx + i] = i < d2 ? lam[i] : 0.f;
+    // through W = rescale tanh(scale raw + shift) + reshift + 1e-8 (and ldj = tr W)
+    const float sc = scal4[0], sh = scal4[1], rs = scal4[2];
+    const float gl = dldj[row];
+    float g_sc = 0.f, g_sh = 0.f, g_rs = 0.f, g_rsh = 0.f;
+    float* dr = dout + (size_t)row * lddo;
+    for (int i = 0; i < d2; ++i)
+        for (int j = 0; j < d2; ++j) {
+            const float gw = dA[i * EX_D + j] + (i == j ? gl : 0.f);
+            const float raw = pr[i * d2 + j];
+            const float t = tanhf(sc * raw + sh);
+            const float gt = gw * rs * (1.0f - t * t);
+            dr[i * d2 + j] = gt * sc;
+            g_sc += gt * raw; g_sh += gt; g_rs += gw * t; g_rsh += gw;
+        }
+    for (int i = 0; i < d2; ++i) dr[d2 * d2 + i] = dy2[(size_t)row * lddy + i];
+    for (int c = d2 * d2 + d2; c < no_pad; ++c) dr[c] = 0.f;
+    dscal[(size_t)row * 4 + 0] = g_sc; dscal[(size_t)row * 4 + 1] = g_sh; dscal[(size_t)row * 4 + 2] = g_rs; dscal[(size_t)row * 4 + 3] = g_rsh;
+}
+
 template <int K>
 static void spline_fwd_k(const float* x2, int ldx, const float* params, int ldp, float* y2, int ldy, float* ldj, int rows, int d2, hipStream_t s) {
     ProfScope ps("fc::spline_train_fwd_kernel", 0.0, (double)rows * d2 * (3 * K + 3) * 4.0, s);
@@ -498,6 +635,32 @@ int fc_train_normlp_bwd_f32(const float* v, int32_t ldv, const float* p, int32_t
     ProfScope ps("fc::normlp_train_bwd_kernel", 0.0, (double)rows * nz * 24.0, s);
     hipLaunchKernelGGL(normlp_train_bwd_kernel, dim3(rows), dim3(256), 0, s, v, ldv, p, ldp, g, dv, lddv, dp, lddp, nz, round_up(nz, 32), round_up(2 * nz, 32),
                        clamp);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_expm_fwd_f32(const float* x2, int32_t ldx, const float* o, int32_t ldo, const float* scal4, float* y2, int32_t ldy, float* ldj, int32_t rows,
+                          int32_t d2, int32_t* status, void* stream) {
+    FC_API_BEGIN
+    if (!x2 || !o || !scal4 || !y2 || !ldj || !status || rows < 1 || d2 < 1 || d2 > EX_D || ldx < d2 || ldo < d2 * d2 + d2 || ldy < round_up(d2, 32))
+        throw Error(FC_ERR_INVALID, "fc_train_expm_fwd_f32: bad argument (d2 <= 16)");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::expm_train_fwd_kernel", 0.0, 0.0, s);
+    hipLaunchKernelGGL(expm_train_fwd_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, x2, ldx, o, ldo, scal4, y2, ldy, ldj, rows, d2, round_up(d2, 32), (int*)status);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+int fc_train_expm_bwd_f32(const float* x2, int32_t ldx, const float* o, int32_t ldo, const float* scal4, const float* dy2, int32_t lddy, const float* dldj,
+                          float* dx2, int32_t lddx, float* dout, int32_t lddo, float* dscal, int32_t rows, int32_t d2, void* stream) {
+    FC_API_BEGIN
+    if (!x2 || !o || !scal4 || !dy2 || !dldj || !dx2 || !dout || !dscal || rows < 1 || d2 < 1 || d2 > EX_D || ldx < d2 || ldo < d2 * d2 + d2 || lddy < d2 ||
+        lddx < round_up(d2, 32) || lddo < round_up(d2 * d2 + d2, 32))
+        throw Error(FC_ERR_INVALID, "fc_train_expm_bwd_f32: bad argument (d2 <= 16)");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::expm_train_bwd_kernel", 0.0, 0.0, s);
+    hipLaunchKernelGGL(expm_train_bwd_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, x2, ldx, o, ldo, scal4, dy2, lddy, dldj, dx2, lddx, dout, lddo, dscal, rows,
+                       d2, round_up(d2, 32), round_up(d2 * d2 + d2, 32));
     FC_HIP(hipGetLastError());
     FC_API_END
 }

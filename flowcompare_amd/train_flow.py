@@ -12,9 +12,9 @@ What runs where
     what torch does on activations is data movement only (pad, slice, cat of panels) and the running sum of the per-point log-dets.
 
 Covered: AugmentAttentionPreconditioner or IdentityTransform; PreConditionApplier with the attention or the global-context
-pre-conditioner; CIFblock (augment / affine_cif / ActNorm / Slice around the coupling); RationalQuadraticSplineCoupling or
-AffineCoupling; ActNormBijectionCloud incl. its first-batch init; LinearLU, random_permute, FullCombiner, ExponentialCombiner; extra
-context.  Not yet: ExponentialCoupling (raises NotImplementedError).
+pre-conditioner; CIFblock (augment / affine_cif / ActNorm / Slice around the coupling); RationalQuadraticSplineCoupling,
+AffineCoupling or ExponentialCoupling (latent_dim - latent_dim // 2 <= 16, as in the inference engine); ActNormBijectionCloud incl. its
+first-batch init; LinearLU, random_permute, FullCombiner, ExponentialCombiner; extra context.
 """
 import math
 
@@ -151,6 +151,8 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
         p = T.mlp_panels(cp.nn, segs, widths, rows, act)
         if isinstance(cp, M.RationalQuadraticSplineCoupling):
             x2, ldj = T.rq_spline(x2, p, rows, d2, cp.num_bins)
+        elif isinstance(cp, M.ExponentialCoupling):
+            x2, ldj = T.expm_coupling(x2, p, cp, rows, d2)
         else:
             x2, ldj = T.affine(x2, p, rows, d2, cp.scale_fn_type)
         return x2, logp + ldj
@@ -232,8 +234,8 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
             inner = blk
         else:
             raise NotImplementedError(f"training path: transform {type(blk).__name__}")
-        if not isinstance(inner.transform, (M.RationalQuadraticSplineCoupling, M.AffineCoupling)):
-            raise NotImplementedError(f"training path: coupling {type(inner.transform).__name__} is not built yet")
+        if not isinstance(inner.transform, (M.RationalQuadraticSplineCoupling, M.AffineCoupling, M.ExponentialCoupling)):
+            raise NotImplementedError(f"training path: coupling {type(inner.transform).__name__}")
         i += 1
         an = perm = None
         if i < len(transforms) and isinstance(transforms[i], M.ActNormBijectionCloud):

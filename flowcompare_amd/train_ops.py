@@ -558,3 +558,47 @@ class EdgeBNMaxFn(torch.autograd.Function):
 
 def edge_bn_max(pq, bn, idx, rows, C, k):
     return EdgeBNMaxFn.apply(pq, bn.weight, bn.bias, idx, rows, C, k, bn)
+
+
+class ExpmCouplingFn(torch.autograd.Function):
+    """ExponentialCoupling element (models/exponential_coupling.py:44-58): x2 panel, o panel [d2*d2 raw matrix | d2 shift], scal4 =
+    cat(scale, shift, rescale, reshift) -> (y2 panel, ldj).  d2 <= 16 (the layer emits d2^2 numbers per point)."""
+
+    @staticmethod
+    def forward(ctx, x2, o, scal4, rows, d2):
+        L = engine.lib()
+        _check_panel(x2, d2)
+        _check_panel(o, d2 * d2 + d2)
+        s4 = scal4.detach().to(torch.float32).contiguous()
+        y2 = _panel_out(x2.shape[0], _round_up(d2, 32), rows, x2.device)
+        ldj = _vec_out(x2.shape[0], rows, x2.device)
+        status = torch.zeros(1, dtype=torch.int32, device=x2.device)
+        with torch.cuda.device(x2.device):
+            engine._check(L.fc_train_expm_fwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(o), o.shape[1], engine._ptr(s4), engine._ptr(y2), y2.shape[1],
+                                                  engine._ptr(ldj), rows, d2, engine._ptr(status), engine._stream()))
+        if int(status.item()):
+            raise RuntimeError("ExponentialCoupling (training): a matrix norm exceeds 2^5; the backward keeps at most 64 squaring states")
+        ctx.save_for_backward(x2, o, s4)
+        ctx.meta = (rows, d2, scal4.dtype)
+        return y2, ldj
+
+    @staticmethod
+    def backward(ctx, dy2, dldj):
+        L = engine.lib()
+        x2, o, s4 = ctx.saved_tensors
+        rows, d2, sdtype = ctx.meta
+        dy2, dldj = dy2.contiguous(), dldj.contiguous()
+        dx2 = _panel_out(x2.shape[0], x2.shape[1], rows, x2.device) if x2.shape[1] == _round_up(d2, 32) else torch.zeros_like(x2)
+        do = _panel_out(o.shape[0], o.shape[1], rows, x2.device) if o.shape[1] == _round_up(d2 * d2 + d2, 32) else torch.zeros_like(o)
+        dscal = torch.zeros(x2.shape[0], 4, dtype=torch.float32, device=x2.device)
+        with torch.cuda.device(x2.device):
+            engine._check(L.fc_train_expm_bwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(o), o.shape[1], engine._ptr(s4), engine._ptr(dy2), dy2.shape[1],
+                                                  engine._ptr(dldj), engine._ptr(dx2), dx2.shape[1], engine._ptr(do), do.shape[1], engine._ptr(dscal), rows,
+                                                  d2, engine._stream()))
+            ds4 = _colsum(dscal, 4, rows).to(sdtype)
+        return dx2, do, ds4, None, None
+
+
+def expm_coupling(x2, o, cp, rows, d2):
+    scal4 = torch.cat((cp.scale.reshape(1), cp.shift.reshape(1), cp.rescale.reshape(1), cp.reshift.reshape(1)))
+    return ExpmCouplingFn.apply(x2, o, scal4, rows, d2)

@@ -266,6 +266,14 @@ int fc_train_gauss_bwd_f32(const float* p, int32_t ldp, const float* eps, const 
 int fc_train_normlp_fwd_f32(const float* v, int32_t ldv, const float* p, int32_t ldp, float* out, int32_t rows, int32_t nz, float clamp, void* stream);
 int fc_train_normlp_bwd_f32(const float* v, int32_t ldv, const float* p, int32_t ldp, const float* g, float* dv, int32_t lddv, float* dp, int32_t lddp,
                             int32_t rows, int32_t nz, float clamp, void* stream);
+/* ExponentialCoupling element (models/exponential_coupling.py:44-58): o = [d2*d2 raw matrix | d2 shift] per point, scal4 = device
+ * (scale, shift, rescale, reshift); y2 = expm(rescale tanh(scale raw + shift) + reshift + 1e-8) x2 + b, ldj = trace.  d2 <= 16.
+ * status (device int32): set when a matrix norm exceeds the 64 squarings the backward keeps states for.
+ * bwd: dscal [rows, 4] = per-point parts of the four scalars' gradients (column sums = the gradients). */
+int fc_train_expm_fwd_f32(const float* x2, int32_t ldx, const float* o, int32_t ldo, const float* scal4, float* y2, int32_t ldy, float* ldj, int32_t rows,
+                          int32_t d2, int32_t* status, void* stream);
+int fc_train_expm_bwd_f32(const float* x2, int32_t ldx, const float* o, int32_t ldo, const float* scal4, const float* dy2, int32_t lddy, const float* dldj,
+                          float* dx2, int32_t lddx, float* dout, int32_t lddo, float* dscal, int32_t rows, int32_t d2, void* stream);
 int fc_train_base_fwd_f32(const float* x, int32_t ldx, float* out, int32_t rows, int32_t width, void* stream);
 int fc_train_base_bwd_f32(const float* x, int32_t ldx, const float* g, float* dx, int32_t lddx, int32_t rows, int32_t width, void* stream);
 size_t fc_train_colsum_ws_bytes(int32_t cols, int32_t rows);

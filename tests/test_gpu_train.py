@@ -495,10 +495,11 @@ def test_two_rank_sharded_training_step_matches_reference_full_batch_gradients()
     assert worst < 1e-4
 
 
-@pytest.mark.parametrize("name", ["e2e_tiny_FullCombiner", "e2e_tiny_ExponentialCombiner"])
+@pytest.mark.parametrize("name", ["e2e_tiny_FullCombiner", "e2e_tiny_ExponentialCombiner", "e2e_tiny_expcoupling", "e2e_tiny_expcoupling_orig"])
 def test_flow_backward_with_dense_combiners_matches_oracle_autograd(name):
-    """FullCombiner / ExponentialCombiner between the layers (models/permuters.py:15-53): their weights are built in parameter space and
-    applied by the training Linear; gradients (incl. w and the tanh-rescale scalars) against fp64 autograd through the pinned oracle."""
+    """FullCombiner / ExponentialCombiner between the layers (models/permuters.py:15-53: weights built in parameter space, applied by
+    the training Linear) and ExponentialCoupling (per-point matrix exponential, reverse mode through the Taylor-action recurrence):
+    gradients (incl. w and the tanh-rescale scalars) against fp64 autograd through the pinned oracle."""
     fx = Fixture(name)
     cfg, md = _build(fx)
     loss, lp, x, ctx = _train_step(fx, cfg, md)
