@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int
     }
     dsum += __shfl_xor(dsum, 32, 64);
     const int ntiles = (p.M + 31) / 32;
+    const float sl2 = p.scale * 1.4426950408889634f;
     const int a_off = li * A16_PITCH + 16 * h;                        // row li, 8 halfs at head dim 8 h of a 16-dim step
     const int tr_off = (4 * h + ((lane & 15) >> 2)) * A16_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     // ---- pass A: log-sum-exp per query (skipped when the forward kernel left it in p.lse)
@@ -299,19 +300,20 @@ __global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool kok = t * 32 + acc_row(r, h) < p.M;
-            sm[r] = kok ? (sm[r] + sc[r] * (1.0f / 2048.0f)) * p.scale : -INFINITY;
+            sm[r] = kok ? (sm[r] + sc[r] * (1.0f / 2048.0f)) * sl2 : -INFINITY;      // log2 domain: exp(x) = exp2(x log2 e), one v_exp_f32
             tmax = fmaxf(tmax, sm[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mn = fmaxf(m, tmax);
         float ts = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ts += expf(sm[r] - mn);
+        for (int r = 0; r < 16; ++r) ts += __builtin_amdgcn_exp2f(sm[r] - mn);
         ts += __shfl_xor(ts, 32, 64);
-        l = l * expf(m - mn) + ts;
+        l = l * __builtin_amdgcn_exp2f(m - mn) + ts;
         m = mn;
     }
-    const float lse = p.have_lse ? p.lse[grow] : m + logf(l);
+    const float lse = p.have_lse ? p.lse[grow] : (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;      // natural log-sum-exp
+    const float lse2 = lse * 1.4426950408889634f;
     if (qok && h == 0) { if (!p.have_lse) p.lse[grow] = lse; p.dvec[grow] = dsum; }
     // ---- pass B: dQ^T[d][query] += K^T dS^T
     f32x16 qm[2], qc[2];
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const bool kok = t * 32 + acc_row(r, h) < p.M;
-            const float pr = kok ? expf((sm[r] + sc[r] * (1.0f / 2048.0f)) * p.scale - lse) : 0.f;
+            const float pr = kok ? __builtin_amdgcn_exp2f((sm[r] + sc[r] * (1.0f / 2048.0f)) * sl2 - lse2) : 0.f;
             dsv[r] = pr * ((pm[r] + pc[r] * (1.0f / 2048.0f)) - dsum) * p.scale;          // dS^T[key][query]
         }
 #pragma unroll
@@ -392,6 +394,7 @@ __global__ __launch_bounds__(256) void attn_bwd16_dkv_kernel(AttnBwdParams p, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) { km[i][r] = 0.f; kc[i][r] = 0.f; vm[i][r] = 0.f; vc[i][r] = 0.f; }
     const int ntiles = (p.N + 31) / 32;
+    const float sl2 = p.scale * 1.4426950408889634f;
     const size_t q0 = (size_t)b * p.N;
     const int a_off = li * A16_PITCH + 16 * h;
     const int tr_off = (4 * h + ((lane & 15) >> 2)) * A16_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256) void attn_bwd16_dkv_kernel(AttnBwdParams p, in
         amax = fmaxf(amax, stage_limbs(p.dout + q0 * p.lddo, p.lddo, t * 32, p.N, sG, tid));
         if (tid < 32) {
             const int qi = t * 32 + tid;
-            sLse[tid] = qi < p.N ? p.lse[q0 + qi] : INFINITY;        // exp(s - inf) = 0: queries past the end contribute nothing
+            sLse[tid] = qi < p.N ? p.lse[q0 + qi] * 1.4426950408889634f : INFINITY;        // log2 domain; exp2(s - inf) = 0: queries past the end contribute nothing
             sD[tid] = qi < p.N ? p.dvec[q0 + qi] : 0.f;
         }
         __syncthreads();
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(256) void attn_bwd16_dkv_kernel(AttnBwdParams p, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = acc_row(r, h);
-            const float pr = kok ? expf((sm[r] + sc[r] * (1.0f / 2048.0f)) * p.scale - sLse[qi]) : 0.f;
+            const float pr = kok ? __builtin_amdgcn_exp2f((sm[r] + sc[r] * (1.0f / 2048.0f)) * sl2 - sLse[qi]) : 0.f;
             pv[r] = pr;
             dsv[r] = pr * ((pm[r] + pc[r] * (1.0f / 2048.0f)) - sD[qi]) * p.scale;
         }
