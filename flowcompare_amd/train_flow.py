@@ -223,6 +223,13 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
             reusable = torch.cuda.memory_reserved(x.device) - torch.cuda.memory_allocated(x.device)      # cached by the allocator, free to us
             activation_budget_bytes = int(0.55 * (free + reusable))
         budget = int(activation_budget_bytes)
+    # which ActNorm layers still wait for their first-batch statistics: ONE device read for the whole stack (a per-layer .item() is a
+    # stream synchronisation per layer, which keeps the host from running ahead of the GPU)
+    actnorms = [m for m in flow.modules() if isinstance(m, M.ActNormBijectionCloud)]
+    uninitialised = {}
+    if actnorms:
+        flags = torch.cat([m.initialized.reshape(1).to(torch.float32) for m in actnorms]).cpu()
+        uninitialised = {id(m): bool(flags[j].item() == 0.0) for j, m in enumerate(actnorms)}
     i = 1
     while i < len(transforms):
         blk = transforms[i]
@@ -247,8 +254,8 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
         elif i < len(transforms) and not isinstance(transforms[i], (M.PreConditionApplier, M.CIFblock)):
             raise NotImplementedError(f"training path: transform {type(transforms[i]).__name__} between layers")
         # un-initialised ActNorm layers take their statistics from this batch, in training mode only (act_norm.py:38-39)
-        init_an = an is not None and float(an.initialized.item()) == 0.0
-        init_cif = isinstance(blk, M.CIFblock) and float(blk.act_norm.initialized.item()) == 0.0
+        init_an = an is not None and uninitialised.get(id(an), False)
+        init_cif = isinstance(blk, M.CIFblock) and uninitialised.get(id(blk.act_norm), False)
         if (init_an or init_cif) and not flow.training:
             init_an = init_cif = False
         e = None

@@ -75,6 +75,24 @@ def _ws(nbytes, device):
         return t
 
 
+class _OnDevice:
+    """`with _OnDevice(dev)` costs ~10 us of host time per entry, and a training step enters it ~20 000 times: the step is
+    partly host-bound, so the switch is skipped when `dev` is already the current device (the normal one-process-per-GPU case)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        idx = dev.index if isinstance(dev, torch.device) else torch.device(dev).index
+        self.ctx = None if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 def _panel_out(rows_pad, cols, rows, device):
     """Uninitialised [rows_pad, cols] panel whose pad ROWS are zeroed (the row-wise kernels write `rows` rows, pad columns included);
     at the bench sizes rows == rows_pad and nothing is filled."""
@@ -122,7 +140,7 @@ class LinearActFn(torch.autograd.Function):
         b32 = None if bias is None else bias.detach().to(torch.float32).contiguous()
         segs = _segs(widths)
         N_pad = _round_up(N, 32)
-        with torch.cuda.device(dev):
+        with _OnDevice(dev):
             nb = L.fc_train_linear_pack_bytes(N, segs, len(widths))
             pack = torch.empty(nb, dtype=torch.uint8, device=dev)
             s = engine._stream()
@@ -154,7 +172,7 @@ class LinearActFn(torch.autograd.Function):
         dy = dy.contiguous()
         segs = _segs(widths)
         need = ctx.needs_input_grad
-        with torch.cuda.device(dev):
+        with _OnDevice(dev):
             s = engine._stream()
             if act:
                 du = torch.empty_like(dy)
@@ -232,7 +250,7 @@ class AttentionFn(torch.autograd.Function):
                 raise RuntimeError("AttentionFn: panel smaller than B * points, or head dims differ")
         dev = q.device
         out = _panel_out(q.shape[0], D, B * N, dev)
-        with torch.cuda.device(dev):
+        with _OnDevice(dev):
             nb = L.fc_train_attention_ws_bytes(B, N, M, D)
             ws = _ws(nb, dev) if _Step.flag is not None else None
             stats = torch.empty(2 * B * N, dtype=torch.float32, device=dev)
@@ -252,7 +270,7 @@ class AttentionFn(torch.autograd.Function):
         dout = dout.contiguous()
         dq = _panel_out(q.shape[0], D, B * N, q.device)
         dk, dv = _panel_out(k.shape[0], D, B * M, q.device), _panel_out(k.shape[0], D, B * M, q.device)
-        with torch.cuda.device(q.device):
+        with _OnDevice(q.device):
             engine._check(L.fc_train_attention_bwd_f32(engine._ptr(q), D, engine._ptr(k), D, engine._ptr(v), D, engine._ptr(out), D,
                                                        engine._ptr(dout), D, engine._ptr(dq), D, engine._ptr(dk), D, engine._ptr(dv), D,
                                                        engine._ptr(stats), stats_valid if _Step.flag is not None else 0, B, N, M, D,
@@ -275,7 +293,7 @@ class SplineFn(torch.autograd.Function):
         _check_panel(params, d2 * (3 * K + 1))
         y2 = _panel_out(x2.shape[0], _round_up(d2, 32), rows, x2.device)
         ldj = _vec_out(x2.shape[0], rows, x2.device)
-        with torch.cuda.device(x2.device):
+        with _OnDevice(x2.device):
             engine._check(L.fc_train_rqspline_fwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(params), params.shape[1], engine._ptr(y2),
                                                       y2.shape[1], engine._ptr(ldj), rows, d2, K, engine._stream()))
         ctx.save_for_backward(x2, params)
@@ -291,7 +309,7 @@ class SplineFn(torch.autograd.Function):
         dx2 = _panel_out(x2.shape[0], x2.shape[1], rows, x2.device) if x2.shape[1] == _round_up(d2, 32) else torch.zeros_like(x2)
         dparams = (_panel_out(params.shape[0], params.shape[1], rows, x2.device) if params.shape[1] == _round_up(d2 * (3 * K + 1), 32)
                    else torch.zeros_like(params))
-        with torch.cuda.device(x2.device):
+        with _OnDevice(x2.device):
             engine._check(L.fc_train_rqspline_bwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(params), params.shape[1], engine._ptr(dy2),
                                                       dy2.shape[1], engine._ptr(dldj), engine._ptr(dx2), dx2.shape[1], engine._ptr(dparams),
                                                       dparams.shape[1], rows, d2, K, engine._stream()))
@@ -323,7 +341,7 @@ class LayerNormFn(torch.autograd.Function):
         y = _panel_out(x.shape[0], _round_up(width, 32), rows, x.device)
         stats = torch.empty(2 * rows, dtype=torch.float32, device=x.device)
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        with torch.cuda.device(x.device):
+        with _OnDevice(x.device):
             engine._check(L.fc_train_layernorm_fwd_f32(engine._ptr(x), x.shape[1], engine._ptr(g32), engine._ptr(b32), engine._ptr(y), y.shape[1],
                                                        engine._ptr(stats), rows, width, ctypes.c_float(eps), engine._stream()))
         ctx.save_for_backward(x, g32, stats)
@@ -341,7 +359,7 @@ class LayerNormFn(torch.autograd.Function):
         if x.shape[1] != wp:
             dx.zero_()
         t = torch.empty(x.shape[0], wp, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _OnDevice(x.device):
             engine._check(L.fc_train_layernorm_bwd_f32(engine._ptr(x), x.shape[1], engine._ptr(g32), engine._ptr(dy), dy.shape[1], engine._ptr(stats),
                                                        engine._ptr(dx), dx.shape[1], engine._ptr(t), wp, x.shape[0], rows, width, engine._stream()))
             dgamma = _colsum(t, width, rows).to(pdtype)
@@ -366,7 +384,7 @@ class AffineFn(torch.autograd.Function):
         _check_panel(st, 2 * d2)
         y2 = _panel_out(x2.shape[0], _round_up(d2, 32), rows, x2.device)
         ldj = _vec_out(x2.shape[0], rows, x2.device)
-        with torch.cuda.device(x2.device):
+        with _OnDevice(x2.device):
             engine._check(L.fc_train_affine_fwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(st), st.shape[1], engine._ptr(y2), y2.shape[1],
                                                     engine._ptr(ldj), rows, d2, scale_fn, engine._stream()))
         ctx.save_for_backward(x2, st)
@@ -381,7 +399,7 @@ class AffineFn(torch.autograd.Function):
         dy2, dldj = dy2.contiguous(), dldj.contiguous()
         dx2 = _panel_out(x2.shape[0], x2.shape[1], rows, x2.device) if x2.shape[1] == _round_up(d2, 32) else torch.zeros_like(x2)
         dst = _panel_out(st.shape[0], st.shape[1], rows, x2.device) if st.shape[1] == _round_up(2 * d2, 32) else torch.zeros_like(st)
-        with torch.cuda.device(x2.device):
+        with _OnDevice(x2.device):
             engine._check(L.fc_train_affine_bwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(st), st.shape[1], engine._ptr(dy2), dy2.shape[1],
                                                     engine._ptr(dldj), engine._ptr(dx2), dx2.shape[1], engine._ptr(dst), dst.shape[1], rows, d2,
                                                     scale_fn, engine._stream()))
@@ -403,7 +421,7 @@ class GaussDrawFn(torch.autograd.Function):
         eps = eps.to(torch.float32).contiguous()
         z = _panel_out(p.shape[0], _round_up(nz, 32), rows, p.device)
         ldj = _vec_out(p.shape[0], rows, p.device)
-        with torch.cuda.device(p.device):
+        with _OnDevice(p.device):
             engine._check(L.fc_train_gauss_fwd_f32(engine._ptr(p), p.shape[1], engine._ptr(eps), engine._ptr(z), z.shape[1], engine._ptr(ldj), rows, nz,
                                                    ctypes.c_float(clamp), engine._stream()))
         ctx.save_for_backward(p, eps)
@@ -417,7 +435,7 @@ class GaussDrawFn(torch.autograd.Function):
         rows, nz, clamp = ctx.meta
         dz, dldj = dz.contiguous(), dldj.contiguous()
         dp = _panel_out(p.shape[0], p.shape[1], rows, p.device) if p.shape[1] == _round_up(2 * nz, 32) else torch.zeros_like(p)
-        with torch.cuda.device(p.device):
+        with _OnDevice(p.device):
             engine._check(L.fc_train_gauss_bwd_f32(engine._ptr(p), p.shape[1], engine._ptr(eps), engine._ptr(dz), dz.shape[1], engine._ptr(dldj),
                                                    engine._ptr(dp), dp.shape[1], rows, nz, ctypes.c_float(clamp), engine._stream()))
         return dp, None, None, None, None
@@ -436,7 +454,7 @@ class NormalLogProbFn(torch.autograd.Function):
         _check_panel(v, nz)
         _check_panel(p, 2 * nz)
         out = _vec_out(v.shape[0], rows, v.device)
-        with torch.cuda.device(v.device):
+        with _OnDevice(v.device):
             engine._check(L.fc_train_normlp_fwd_f32(engine._ptr(v), v.shape[1], engine._ptr(p), p.shape[1], engine._ptr(out), rows, nz,
                                                     ctypes.c_float(clamp), engine._stream()))
         ctx.save_for_backward(v, p)
@@ -451,7 +469,7 @@ class NormalLogProbFn(torch.autograd.Function):
         g = g.contiguous()
         dv = _panel_out(v.shape[0], v.shape[1], rows, v.device) if v.shape[1] == _round_up(nz, 32) else torch.zeros_like(v)
         dp = _panel_out(p.shape[0], p.shape[1], rows, v.device) if p.shape[1] == _round_up(2 * nz, 32) else torch.zeros_like(p)
-        with torch.cuda.device(v.device):
+        with _OnDevice(v.device):
             engine._check(L.fc_train_normlp_bwd_f32(engine._ptr(v), v.shape[1], engine._ptr(p), p.shape[1], engine._ptr(g), engine._ptr(dv), dv.shape[1],
                                                     engine._ptr(dp), dp.shape[1], rows, nz, ctypes.c_float(clamp), engine._stream()))
         return dv, dp, None, None, None
@@ -469,7 +487,7 @@ class BaseDensityFn(torch.autograd.Function):
         L = engine.lib()
         _check_panel(x, width)
         out = _vec_out(x.shape[0], rows, x.device)
-        with torch.cuda.device(x.device):
+        with _OnDevice(x.device):
             engine._check(L.fc_train_base_fwd_f32(engine._ptr(x), x.shape[1], engine._ptr(out), rows, width, engine._stream()))
         ctx.save_for_backward(x)
         ctx.meta = (rows, width)
@@ -482,7 +500,7 @@ class BaseDensityFn(torch.autograd.Function):
         rows, width = ctx.meta
         g = g.contiguous()
         dx = _panel_out(x.shape[0], x.shape[1], rows, x.device) if x.shape[1] == _round_up(width, 32) else torch.zeros_like(x)
-        with torch.cuda.device(x.device):
+        with _OnDevice(x.device):
             engine._check(L.fc_train_base_bwd_f32(engine._ptr(x), x.shape[1], engine._ptr(g), engine._ptr(dx), dx.shape[1], rows, width, engine._stream()))
         return dx, None, None
 
@@ -510,7 +528,7 @@ class EdgeBNMaxFn(torch.autograd.Function):
         out = _panel_out(pq.shape[0], C, rows, dev)
         arg = torch.empty(rows, C, dtype=torch.uint8, device=dev)
         q_ptr = ctypes.c_void_p(pq.data_ptr() + 4 * C) if has_q else ctypes.c_void_p(0)
-        with torch.cuda.device(dev):
+        with _OnDevice(dev):
             s = engine._stream()
             nb = L.fc_train_edge_ws_bytes(rows, C)
             ws = _ws(nb, dev)
@@ -543,7 +561,7 @@ class EdgeBNMaxFn(torch.autograd.Function):
         t1 = torch.empty(rows_pad, C, dtype=torch.float32, device=dev)
         t2 = torch.empty(rows_pad, C, dtype=torch.float32, device=dev)
         dpq = torch.zeros_like(pq)                                  # dP accumulates by atomics
-        with torch.cuda.device(dev):
+        with _OnDevice(dev):
             s = engine._stream()
             engine._check(L.fc_train_edge_bwd_prep_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats), engine._ptr(g32),
                                                        engine._ptr(b32), engine._ptr(arg), engine._ptr(g), g.shape[1], engine._ptr(t1), engine._ptr(t2),
@@ -573,7 +591,7 @@ class ExpmCouplingFn(torch.autograd.Function):
         y2 = _panel_out(x2.shape[0], _round_up(d2, 32), rows, x2.device)
         ldj = _vec_out(x2.shape[0], rows, x2.device)
         status = torch.zeros(1, dtype=torch.int32, device=x2.device)
-        with torch.cuda.device(x2.device):
+        with _OnDevice(x2.device):
             engine._check(L.fc_train_expm_fwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(o), o.shape[1], engine._ptr(s4), engine._ptr(y2), y2.shape[1],
                                                   engine._ptr(ldj), rows, d2, engine._ptr(status), engine._stream()))
         if int(status.item()):
@@ -591,7 +609,7 @@ class ExpmCouplingFn(torch.autograd.Function):
         dx2 = _panel_out(x2.shape[0], x2.shape[1], rows, x2.device) if x2.shape[1] == _round_up(d2, 32) else torch.zeros_like(x2)
         do = _panel_out(o.shape[0], o.shape[1], rows, x2.device) if o.shape[1] == _round_up(d2 * d2 + d2, 32) else torch.zeros_like(o)
         dscal = torch.zeros(x2.shape[0], 4, dtype=torch.float32, device=x2.device)
-        with torch.cuda.device(x2.device):
+        with _OnDevice(x2.device):
             engine._check(L.fc_train_expm_bwd_f32(engine._ptr(x2), x2.shape[1], engine._ptr(o), o.shape[1], engine._ptr(s4), engine._ptr(dy2), dy2.shape[1],
                                                   engine._ptr(dldj), engine._ptr(dx2), dx2.shape[1], engine._ptr(do), do.shape[1], engine._ptr(dscal), rows,
                                                   d2, engine._stream()))
