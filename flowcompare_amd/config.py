@@ -22,6 +22,8 @@ DEFAULTS = dict(
     input_embedder="DGCNNembedder", extra_z_value_context=False, num_bins_spline=8,
     eps_expm=1.0e-8, coupling_expm_algo="torch", clamp_dist=10.0, data_parallel=False, amp=False,
     cif_dist="ConditionalNormal", load_checkpoint=False,
+    # training loop (train.py:44-60, 112-120; values of the reference's shipped yaml files)
+    optimizer_type="Adam", lr=1.0e-4, weight_decay=0.0, grad_clip_val=1.0, min_lr=1.0e-10, lr_factor=0.8, patience=2000, batch_size=20,
 )
 
 CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
