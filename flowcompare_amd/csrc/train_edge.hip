@@ -8,8 +8,8 @@
 //   edge_fwd      out[i][c] = max_j lrelu(gamma (y_ij - mean) rstd + beta), arg[i][c] = argmax j
 //   edge_bwd_prep t1 = g lrelu'(u*) and t2 = t1 xhat* at the argmax: their column sums are d beta and d gamma
 //   edge_bwd_scatter  dy_ij = gamma rstd ([j = j*] t1 - d beta / n - xhat_ij d gamma / n) for EVERY (i, j) (batch statistics couple all
-//                 of them), dQ[i] = sum_j dy_ij, dP[idx_ij] += dy_ij (float atomics: the one place of the training path whose
-//                 summation order is not fixed)
+//                 of them), dQ[i] = sum_j dy_ij, dP[idx_ij] += dy_ij by float atomics -- or, given the edges sorted by target
+//                 (edge_bwd_gather), as an owner-computes sum in a fixed order: the path the training embedder takes
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -121,10 +121,36 @@ __global__ __launch_bounds__(256) void edge_bwd_scatter_kernel(EdgeParams e, con
             const float xh = (e.P[(size_t)src * e.ldp + c] + (e.Q ? e.Q[(size_t)i * e.ldq + c] : 0.f) - mean) * rstd;
             const float dy = a * ((j == js ? tv : 0.f) - mb - xh * mg);
             dq += dy;
+            if (!dP) continue;                                   // dP comes from edge_bwd_gather_kernel (fixed summation order)
             if (e.idx) atomicAdd(dP + (size_t)src * lddp + c, dy);
             else dP[(size_t)src * lddp + c] = dy;
         }
         if (dQ) dQ[(size_t)i * lddq + c] = dq;
+    }
+}
+
+// dP[m][c] = sum of dy_ij over the edges (i, j) that point at row m, visited in the order of `order` (edge ids i k + j sorted by target,
+// stable): every target row is owned by one wave and summed in a fixed order -- the deterministic counterpart of the atomics above
+__global__ __launch_bounds__(256) void edge_bwd_gather_kernel(EdgeParams e, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const unsigned char* __restrict__ arg, const float* __restrict__ t1, int ldt,
+                                                              const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_n,
+                                                              const int* __restrict__ order, const int* __restrict__ offsets, float* __restrict__ dP,
+                                                              int lddp) {
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + q;
+    if (m >= e.rows) return;
+    const int e0 = offsets[m], e1 = offsets[m + 1];
+    for (int c = lane; c < e.C; c += 64) {
+        const float mean = stats[c], rstd = stats[e.C + c];
+        const float a = gamma[c] * rstd, mb = dbeta[c] * inv_n, mg = dgamma[c] * inv_n;
+        const float pm = e.P[(size_t)m * e.ldp + c];
+        float acc = 0.f;
+        for (int t = e0; t < e1; ++t) {
+            const int ed = order[t], i = ed / e.k, j = ed - i * e.k;
+            const float xh = (pm + (e.Q ? e.Q[(size_t)i * e.ldq + c] : 0.f) - mean) * rstd;
+            acc += a * ((j == arg[(size_t)i * e.C + c] ? t1[(size_t)i * ldt + c] : 0.f) - mb - xh * mg);
+        }
+        dP[(size_t)m * lddp + c] = acc;
     }
 }
 
@@ -199,11 +225,29 @@ int fc_train_edge_bwd_scatter_f32(const float* P, int32_t ldp, const float* Q, i
                                   const float* dgamma, float* dP, int32_t lddp, float* dQ, int32_t lddq, void* stream) {
     FC_API_BEGIN
     const EdgeParams e = edge_params(P, ldp, Q, ldq, idx, rows, k, C, "fc_train_edge_bwd_scatter_f32");
-    if (!stats || !gamma || !arg || !t1 || !dbeta || !dgamma || !dP || ldt < C || lddp < C || (dQ && lddq < C)) throw Error(FC_ERR_INVALID, "fc_train_edge_bwd_scatter_f32: bad argument");
+    if (!stats || !gamma || !arg || !t1 || !dbeta || !dgamma || (!dP && !dQ) || ldt < C || (dP && lddp < C) || (dQ && lddq < C))
+        throw Error(FC_ERR_INVALID, "fc_train_edge_bwd_scatter_f32: bad argument");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("fc::edge_bwd_scatter_kernel", 0.0, (double)rows * k * C * 8.0, s);
     hipLaunchKernelGGL(edge_bwd_scatter_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, e, stats, gamma, arg, t1, ldt, dbeta, dgamma,
                        (float)(1.0 / ((double)rows * k)), dP, lddp, dQ, lddq);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+/* Deterministic dP: order [rows * k] = edge ids (i * k + j) sorted by the row they point at (stable), offsets [rows + 1] = start of each
+ * row's segment.  Use together with fc_train_edge_bwd_scatter_f32(dP = NULL) for dQ. */
+int fc_train_edge_bwd_gather_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
+                                 const float* stats, const float* gamma, const uint8_t* arg, const float* t1, int32_t ldt, const float* dbeta,
+                                 const float* dgamma, const int32_t* order, const int32_t* offsets, float* dP, int32_t lddp, void* stream) {
+    FC_API_BEGIN
+    const EdgeParams e = edge_params(P, ldp, Q, ldq, idx, rows, k, C, "fc_train_edge_bwd_gather_f32");
+    if (!idx || !stats || !gamma || !arg || !t1 || !dbeta || !dgamma || !order || !offsets || !dP || ldt < C || lddp < C)
+        throw Error(FC_ERR_INVALID, "fc_train_edge_bwd_gather_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::edge_bwd_gather_kernel", 0.0, (double)rows * k * C * 8.0, s);
+    hipLaunchKernelGGL(edge_bwd_gather_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, e, stats, gamma, arg, t1, ldt, dbeta, dgamma,
+                       (float)(1.0 / ((double)rows * k)), order, offsets, dP, lddp);
     FC_HIP(hipGetLastError());
     FC_API_END
 }

@@ -544,14 +544,21 @@ class EdgeBNMaxFn(torch.autograd.Function):
                 bn.running_mean.mul_(1 - m).add_(stats[:C].to(bn.running_mean.dtype), alpha=m)
                 bn.running_var.mul_(1 - m).add_(stats[2 * C:].to(bn.running_var.dtype) * (n / max(n - 1, 1)), alpha=m)
                 bn.num_batches_tracked += 1
-        ctx.save_for_backward(pq, g32, b32, stats, arg, idx)
+        order = offsets = None
+        if has_q:
+            # edges sorted by the row they point at (index plumbing): the backward then sums each row's incoming gradients in a fixed order
+            flat = idx.reshape(-1).long()
+            order = torch.argsort(flat, stable=True).to(torch.int32)
+            offsets = torch.zeros(rows + 1, dtype=torch.int32, device=dev)
+            offsets[1:] = torch.cumsum(torch.bincount(flat, minlength=rows), 0).to(torch.int32)
+        ctx.save_for_backward(pq, g32, b32, stats, arg, idx, order, offsets)
         ctx.meta = (rows, C, k, has_q, gamma.dtype)
         return out
 
     @staticmethod
     def backward(ctx, g):
         L = engine.lib()
-        pq, g32, b32, stats, arg, idx = ctx.saved_tensors
+        pq, g32, b32, stats, arg, idx, order, offsets = ctx.saved_tensors
         rows, C, k, has_q, pdtype = ctx.meta
         dev = pq.device
         g = g.contiguous()
@@ -560,7 +567,7 @@ class EdgeBNMaxFn(torch.autograd.Function):
         rows_pad = pq.shape[0]
         t1 = torch.empty(rows_pad, C, dtype=torch.float32, device=dev)
         t2 = torch.empty(rows_pad, C, dtype=torch.float32, device=dev)
-        dpq = torch.zeros_like(pq)                                  # dP accumulates by atomics
+        dpq = torch.zeros_like(pq)
         with _OnDevice(dev):
             s = engine._stream()
             engine._check(L.fc_train_edge_bwd_prep_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats), engine._ptr(g32),
@@ -568,9 +575,18 @@ class EdgeBNMaxFn(torch.autograd.Function):
                                                        C, rows_pad, s))
             dbeta, dgamma = _colsum(t1, C, rows), _colsum(t2, C, rows)
             dq_ptr = ctypes.c_void_p(dpq.data_ptr() + 4 * C) if has_q else ctypes.c_void_p(0)
-            engine._check(L.fc_train_edge_bwd_scatter_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats),
-                                                          engine._ptr(g32), engine._ptr(arg), engine._ptr(t1), C, engine._ptr(dbeta), engine._ptr(dgamma),
-                                                          engine._ptr(dpq), ld, dq_ptr, ld, s))
+            if has_q:
+                # dQ by row sums, dP by an owner-computes gather over the sorted edges: no atomics, bit-reproducible
+                engine._check(L.fc_train_edge_bwd_scatter_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats),
+                                                              engine._ptr(g32), engine._ptr(arg), engine._ptr(t1), C, engine._ptr(dbeta),
+                                                              engine._ptr(dgamma), ctypes.c_void_p(0), ld, dq_ptr, ld, s))
+                engine._check(L.fc_train_edge_bwd_gather_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats),
+                                                             engine._ptr(g32), engine._ptr(arg), engine._ptr(t1), C, engine._ptr(dbeta),
+                                                             engine._ptr(dgamma), engine._ptr(order), engine._ptr(offsets), engine._ptr(dpq), ld, s))
+            else:
+                engine._check(L.fc_train_edge_bwd_scatter_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats),
+                                                              engine._ptr(g32), engine._ptr(arg), engine._ptr(t1), C, engine._ptr(dbeta),
+                                                              engine._ptr(dgamma), engine._ptr(dpq), ld, dq_ptr, ld, s))
         return dpq, dgamma.to(pdtype), dbeta.to(pdtype), None, None, None, None, None
 
 

@@ -284,7 +284,8 @@ int fc_train_colsum_f32(const float* a, int32_t lda, int32_t cols, int32_t rows,
  * conv of cat(f_j - f_i, f_i) split by linearity into two per-point products), BatchNorm with batch statistics over all (i, j),
  * LeakyReLU(0.2), max over the k neighbours -- forward and backward.  idx [rows, k] holds GLOBAL row indices (k <= 255); idx == NULL
  * with k == 1 and Q == NULL is BatchNorm1d + LeakyReLU on a [rows, C] matrix (conv5).  stats [3C] = mean | rstd | biased variance.
- * bwd: prep -> column sums of t1, t2 (fc_train_colsum_f32) = d beta, d gamma -> scatter (dP zeroed by the caller; float atomics). */
+ * bwd: prep -> column sums of t1, t2 (fc_train_colsum_f32) = d beta, d gamma -> scatter (dQ; dP by float atomics into a zeroed buffer, or
+ * dP = NULL and fc_train_edge_bwd_gather_f32 over the edges sorted by target: fixed summation order, bit-reproducible). */
 size_t fc_train_edge_ws_bytes(int32_t rows, int32_t C);
 int fc_train_edge_stats_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C, float eps,
                             float* stats, void* ws, size_t ws_bytes, void* stream);
@@ -293,6 +294,9 @@ int fc_train_edge_fwd_f32(const float* P, int32_t ldp, const float* Q, int32_t l
 int fc_train_edge_bwd_prep_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
                                const float* stats, const float* gamma, const float* beta, const uint8_t* arg, const float* g, int32_t ldg, float* t1,
                                float* t2, int32_t ldt, int32_t rows_pad, void* stream);
+int fc_train_edge_bwd_gather_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
+                                 const float* stats, const float* gamma, const uint8_t* arg, const float* t1, int32_t ldt, const float* dbeta,
+                                 const float* dgamma, const int32_t* order, const int32_t* offsets, float* dP, int32_t lddp, void* stream);
 int fc_train_edge_bwd_scatter_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
                                   const float* stats, const float* gamma, const uint8_t* arg, const float* t1, int32_t ldt, const float* dbeta,
                                   const float* dgamma, float* dP, int32_t lddp, float* dQ, int32_t lddq, void* stream);

@@ -575,3 +575,27 @@ def test_five_adam_steps_follow_the_oracle_trajectory():
     assert worst < 1e-3
     md["flow"].eval()
     md["input_embedder"].eval()
+
+
+def test_full_training_step_is_bit_reproducible():
+    """Two runs of the whole train-mode step (embedder with batch-statistics BatchNorm + flow) give bit-identical gradients: every
+    reduction of the backward has a fixed order, the EdgeConv input gradient included (owner-computes gather over the edges sorted by
+    target instead of atomics)."""
+    fx = Fixture("e2e_spline_L2")
+    cfg, md = _build(fx)
+    md["flow"].train()
+    md["input_embedder"].train()
+    batch = tuple(None if t is None else t.to(DEV) for t in (fx.t("extract_0"), fx.t("extract_1"), fx.t("extra")))
+    eps = [e.to(DEV) for e in fx.eps()]
+    runs = []
+    for _ in range(2):
+        for m in (md["flow"], md["input_embedder"]):
+            m.zero_grad()
+        with T.step_guard(device=DEV) as guard:
+            loss, _, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+            loss.backward()
+            assert not guard.overflowed()
+        runs.append({f"{part}/{n}": p.grad.clone() for part in ("flow", "input_embedder") for n, p in md[part].named_parameters() if p.grad is not None})
+    assert len(runs[0]) > 90 and all(torch.equal(runs[0][k], runs[1][k]) for k in runs[0])
+    md["flow"].eval()
+    md["input_embedder"].eval()
