@@ -97,10 +97,18 @@ def interpolation(feat_cf, idx, weight):
 
 # ------------------------------------------------------------------ network (pure PyTorch in the reference)
 def _bn(sd, p, x, dim=1):
+    """BatchNorm over channel axis `dim`: running statistics in eval mode, the batch's biased statistics inside
+    flow_oracle.train_mode() (module.train())."""
+    from . import flow_oracle
     shape = [1] * x.dim()
     shape[dim] = -1
-    inv = torch.rsqrt(sd[f"{p}.running_var"] + 1e-5)
-    return (x - sd[f"{p}.running_mean"].reshape(shape)) * (inv * sd[f"{p}.weight"]).reshape(shape) + sd[f"{p}.bias"].reshape(shape)
+    if flow_oracle.BN_BATCH_STATS:
+        red = tuple(d for d in range(x.dim()) if d != dim)
+        mean, var = x.mean(red), x.var(red, unbiased=False)
+    else:
+        mean, var = sd[f"{p}.running_mean"], sd[f"{p}.running_var"]
+    inv = torch.rsqrt(var + 1e-5)
+    return (x - mean.reshape(shape)) * (inv * sd[f"{p}.weight"]).reshape(shape) + sd[f"{p}.bias"].reshape(shape)
 
 
 def scorenet(sd, p, xyz_diff):

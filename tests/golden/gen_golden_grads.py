@@ -28,7 +28,7 @@ sys.path.insert(0, HERE)
 import gen_golden as G      # noqa: E402  (imports the reference)
 import synth                # noqa: E402
 
-CASES = ["e2e_tiny_affine", "e2e_tiny_spline_relu", "e2e_tiny_cif", "e2e_tiny_global_extra", "e2e_tiny_random_permute", "e2e_spline_L2"]
+CASES = ["e2e_tiny_affine", "e2e_tiny_spline_relu", "e2e_tiny_cif", "e2e_tiny_global_extra", "e2e_tiny_random_permute", "e2e_spline_L2", "e2e_paconv_L2"]
 HEAD = 8
 
 
@@ -111,5 +111,6 @@ def grad_case(case):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    G.patch_pointops()          # PAConv's six CUDA kernels -> the oracle's CPU restatements (as for the forward fixtures, gen_golden.py)
     for c in CASES:
         grad_case(c)

@@ -15,7 +15,7 @@ from conftest import GOLDEN, Fixture
 from oracle import flow_oracle as O
 import synth
 
-CASES = ["tiny_affine", "tiny_spline_relu", "tiny_cif", "tiny_global_extra", "tiny_random_permute", "spline_L2"]
+CASES = ["tiny_affine", "tiny_spline_relu", "tiny_cif", "tiny_global_extra", "tiny_random_permute", "spline_L2", "paconv_L2"]
 HEAD = 8
 
 
