@@ -26,6 +26,14 @@ void set_last_error(const std::string& m);
             throw fc::Error(FC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+// Every extern "C" entry point: exceptions -> status code + fc_last_error() text (the C ABI never throws, never exits).
+#define FC_API_BEGIN try {
+#define FC_API_END                                                                            \
+    }                                                                                         \
+    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }               \
+    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; }  \
+    return FC_OK;
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
 

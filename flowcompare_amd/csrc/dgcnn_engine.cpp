@@ -155,12 +155,6 @@ static void dgcnn_forward(fc_dgcnn& e, const float* pts, float* out, int B, int 
 const char* get_last_error();
 }  // namespace fc
 
-#define FC_API_BEGIN try {
-#define FC_API_END                                                    \
-    }                                                                 \
-    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }          \
-    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; } \
-    return FC_OK;
 
 extern "C" {
 

@@ -786,12 +786,6 @@ static void flow_inverse(fc_flow& f, const float* z, const float* ctx, const flo
 // ================================================================== C ABI
 namespace fc { const char* get_last_error(); void prof_set(bool); void prof_reset(); std::string prof_report_json(); }
 
-#define FC_API_BEGIN try {
-#define FC_API_END                                                    \
-    }                                                                 \
-    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }          \
-    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; } \
-    return FC_OK;
 
 extern "C" {
 

@@ -15,12 +15,6 @@ struct TmpBuf {
 };
 }  // namespace fc
 
-#define FC_API_BEGIN try {
-#define FC_API_END                                                    \
-    }                                                                 \
-    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }          \
-    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; } \
-    return FC_OK;
 
 namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }

@@ -269,12 +269,6 @@ static void paconv_forward(fc_paconv& e, const float* pts, float* out, int B, in
 
 }  // namespace fc
 
-#define FC_API_BEGIN try {
-#define FC_API_END                                                    \
-    }                                                                 \
-    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }          \
-    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; } \
-    return FC_OK;
 
 extern "C" {
 

@@ -491,12 +491,6 @@ static void check_panel(const void* p, int ld, int width_pad, const char* what) 
 
 }  // namespace fc
 
-#define FC_API_BEGIN try {
-#define FC_API_END                                                                            \
-    }                                                                                         \
-    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }               \
-    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; }  \
-    return FC_OK;
 
 using namespace fc;
 

@@ -490,12 +490,6 @@ bool launch_attention_scaled_op(const float* q, int ldq, const float* k, int ldk
 
 using namespace fc;
 
-#define FC_API_BEGIN try {
-#define FC_API_END                                                                            \
-    }                                                                                         \
-    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }               \
-    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; }  \
-    return FC_OK;
 
 static void check_mat(const void* p, int ld, int D, const char* what) {
     if (!p || ld < D || ld % 4 != 0 || ((uintptr_t)p & 15)) throw Error(FC_ERR_INVALID, std::string("training attention: bad matrix ") + what);

@@ -160,12 +160,6 @@ static int edge_chunks(int rows) { return std::max(1, std::min(512, rows / 64));
 
 using namespace fc;
 
-#define FC_API_BEGIN try {
-#define FC_API_END                                                                            \
-    }                                                                                         \
-    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }               \
-    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; }  \
-    return FC_OK;
 
 static EdgeParams edge_params(const float* P, int ldp, const float* Q, int ldq, const int32_t* idx, int rows, int k, int C, const char* who) {
     if (!P || rows < 1 || C < 1 || ldp < C || (Q && ldq < C) || k < 1 || k > 255 || (!idx && k != 1))

@@ -501,12 +501,6 @@ static void spline_bwd_k(const float* x2, int ldx, const float* params, int ldp,
 
 using namespace fc;
 
-#define FC_API_BEGIN try {
-#define FC_API_END                                                                            \
-    }                                                                                         \
-    catch (const fc::Error& e) { fc::set_last_error(e.what()); return e.code; }               \
-    catch (const std::exception& e) { fc::set_last_error(e.what()); return FC_ERR_INVALID; }  \
-    return FC_OK;
 
 extern "C" {
 
