@@ -25,7 +25,7 @@ from . import modules as M
 from . import train_ops as T
 
 LOG_2PI = math.log(2.0 * math.pi)
-ACTIVATION_BUDGET_BYTES = None      # None: 55 % of the HBM available at call time; 0: checkpoint every layer (flow_log_prob)
+ACTIVATION_BUDGET_BYTES = None      # None: 70 % of the HBM available at call time; 0: checkpoint every layer (flow_log_prob)
 
 
 def _attention_block(pre, h_panel, h_width, ctx_k, ctx_v, rows, B, N, Mctx):
@@ -87,7 +87,7 @@ def _actnorm_data_init(an, parts, rows):
 def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, checkpoint=True, activation_budget_bytes=None):
     """log p(x | context) [B, N] with autograd through HIP kernels.  Arguments as Flow.log_prob (modules.py); `eps` pins the
     augmenter noise; `checkpoint` recomputes a layer's forward during backward for the layers whose saved activations do not fit
-    `activation_budget_bytes` (default: 55 % of the HBM that is free at call time; 0 = checkpoint every layer).
+    `activation_budget_bytes` (default: 70 % of the HBM that is free at call time; 0 = checkpoint every layer).
     Call inside train_ops.step_guard() to run the split-fp16 loops with the range flag."""
     cfg = flow._config
     act = act or cfg["coupling_block_nonlinearity"]
@@ -221,7 +221,7 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
         if activation_budget_bytes is None:
             free, _total = torch.cuda.mem_get_info(x.device)
             reusable = torch.cuda.memory_reserved(x.device) - torch.cuda.memory_allocated(x.device)      # cached by the allocator, free to us
-            activation_budget_bytes = int(0.55 * (free + reusable))
+            activation_budget_bytes = int(0.70 * (free + reusable))
         budget = int(activation_budget_bytes)
     # which ActNorm layers still wait for their first-batch statistics: ONE device read for the whole stack (a per-layer .item() is a
     # stream synchronisation per layer, which keeps the host from running ahead of the GPU)

@@ -24,7 +24,7 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--profile", action="store_true")
 ap.add_argument("--frozen-embedder", action="store_true")
-ap.add_argument("--budget-gb", type=float, default=-1.0, help="activation budget in GB (-1 = default: 55 %% of free HBM, 0 = checkpoint every layer)")
+ap.add_argument("--budget-gb", type=float, default=-1.0, help="activation budget in GB (-1 = default: 70 %% of free HBM, 0 = checkpoint every layer)")
 a = ap.parse_args()
 dev = "cuda:0"
 if a.budget_gb >= 0:
