@@ -154,6 +154,45 @@ __global__ __launch_bounds__(256) void edge_bwd_gather_kernel(EdgeParams e, cons
     }
 }
 
+// ---------------------------------------------------------------- global embedder pooling (models/pytorch_gcn.py:178-182)
+// out[b] = [max_i t[b, i, :] | mean_i t[b, i, :]] with the arg-max kept for the backward; one workgroup per (64 channels, scene)
+__global__ __launch_bounds__(256) void pool_train_fwd_kernel(const float* __restrict__ t, int ldt, int width, int M, float* __restrict__ out, int ldo,
+                                                             int* __restrict__ arg) {
+    __shared__ float smx[4][64], ssum[4][64];
+    __shared__ int sarg[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, part = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+    float mx = -INFINITY, sum = 0.f;
+    int am = 0;
+    if (c < width)
+        for (int i = part; i < M; i += 4) {
+            const float v = t[((size_t)b * M + i) * ldt + c];
+            if (v > mx) { mx = v; am = i; }
+            sum += v;
+        }
+    smx[part][lane] = mx; ssum[part][lane] = sum; sarg[part][lane] = am;
+    __syncthreads();
+    if (part == 0 && c < width) {
+        float best = smx[0][lane];
+        int bi = sarg[0][lane];
+        for (int p = 1; p < 4; ++p)
+            if (smx[p][lane] > best || (smx[p][lane] == best && sarg[p][lane] < bi)) { best = smx[p][lane]; bi = sarg[p][lane]; }
+        out[(size_t)b * ldo + c] = best;
+        out[(size_t)b * ldo + width + c] = ((ssum[0][lane] + ssum[1][lane]) + (ssum[2][lane] + ssum[3][lane])) / (float)M;
+        arg[(size_t)b * width + c] = bi;
+    }
+}
+// dt[b, i, c] = g[b, width + c] / M + (i == arg[b, c] ? g[b, c] : 0)
+__global__ void pool_train_bwd_kernel(const float* __restrict__ g, int ldg, const int* __restrict__ arg, int width, int M, int B, float* __restrict__ dt,
+                                      int lddt) {
+    const size_t total = (size_t)B * M * width;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % width);
+        const size_t r = e / width;
+        const int b = (int)(r / M), i = (int)(r % M);
+        dt[r * lddt + c] = g[(size_t)b * ldg + width + c] / (float)M + (i == arg[(size_t)b * width + c] ? g[(size_t)b * ldg + c] : 0.f);
+    }
+}
+
 static int edge_chunks(int rows) { return std::max(1, std::min(512, rows / 64)); }
 
 }  // namespace fc
@@ -225,6 +264,27 @@ int fc_train_edge_bwd_scatter_f32(const float* P, int32_t ldp, const float* Q, i
     ProfScope ps("fc::edge_bwd_scatter_kernel", 0.0, (double)rows * k * C * 8.0, s);
     hipLaunchKernelGGL(edge_bwd_scatter_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, e, stats, gamma, arg, t1, ldt, dbeta, dgamma,
                        (float)(1.0 / ((double)rows * k)), dP, lddp, dQ, lddq);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+
+/* Global-embedder pooling over a scene's M points: out [B, ldo >= 2 width] = [max | mean], arg [B, width] (int32) for the backward. */
+int fc_train_pool_fwd_f32(const float* t, int32_t ldt, int32_t width, int32_t B, int32_t M, float* out, int32_t ldo, int32_t* arg, void* stream) {
+    FC_API_BEGIN
+    if (!t || !out || !arg || width < 1 || B < 1 || M < 1 || ldt < width || ldo < 2 * width) throw Error(FC_ERR_INVALID, "fc_train_pool_fwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("fc::pool_train_fwd_kernel", 0.0, (double)B * M * width * 4.0, s);
+    hipLaunchKernelGGL(pool_train_fwd_kernel, dim3((width + 63) / 64, B), dim3(256), 0, s, t, ldt, width, M, out, ldo, (int*)arg);
+    FC_HIP(hipGetLastError());
+    FC_API_END
+}
+int fc_train_pool_bwd_f32(const float* g, int32_t ldg, const int32_t* arg, int32_t width, int32_t B, int32_t M, float* dt, int32_t lddt, void* stream) {
+    FC_API_BEGIN
+    if (!g || !arg || !dt || width < 1 || B < 1 || M < 1 || ldg < 2 * width || lddt < width) throw Error(FC_ERR_INVALID, "fc_train_pool_bwd_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)B * M * width;
+    ProfScope ps("fc::pool_train_bwd_kernel", 0.0, (double)total * 4.0, s);
+    hipLaunchKernelGGL(pool_train_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, g, ldg, (const int*)arg, width, M, B, dt, lddt);
     FC_HIP(hipGetLastError());
     FC_API_END
 }

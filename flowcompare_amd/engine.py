@@ -35,7 +35,7 @@ EXPORTS = [
     "fc_train_colsum_ws_bytes", "fc_train_colsum_f32",
     "fc_train_affine_fwd_f32", "fc_train_affine_bwd_f32", "fc_train_gauss_fwd_f32", "fc_train_gauss_bwd_f32", "fc_train_base_fwd_f32", "fc_train_base_bwd_f32",
     "fc_train_normlp_fwd_f32", "fc_train_normlp_bwd_f32", "fc_train_expm_fwd_f32", "fc_train_expm_bwd_f32",
-    "fc_train_edge_ws_bytes", "fc_train_edge_stats_f32", "fc_train_edge_fwd_f32", "fc_train_edge_bwd_prep_f32", "fc_train_edge_bwd_scatter_f32", "fc_train_edge_bwd_gather_f32",
+    "fc_train_edge_ws_bytes", "fc_train_edge_stats_f32", "fc_train_edge_fwd_f32", "fc_train_edge_bwd_prep_f32", "fc_train_edge_bwd_scatter_f32", "fc_train_edge_bwd_gather_f32", "fc_train_pool_fwd_f32", "fc_train_pool_bwd_f32",
 ]
 
 

@@ -3,8 +3,7 @@ through HIP kernels: k-NN graph (inference kernel; indices carry no gradient), t
 per-point products of the training Linear, BatchNorm with batch statistics + LeakyReLU + max over neighbours (csrc/train_edge.hip),
 conv5 + BatchNorm1d, the output MLP.  BatchNorm running statistics are updated as torch does in train mode.
 
-torch on activations: data movement only (dense copies for the k-NN kernel, cat of the four level outputs) and, for the global
-embedder, the max / mean pooling over a scene's points.
+torch on activations: data movement only (dense copies for the k-NN kernel, cat of the four level outputs).
 """
 import torch
 
@@ -37,8 +36,7 @@ def dgcnn_embed(emb, pts):
     y5 = T.linear_act([cat], [cat.shape[1]], emb.conv5[0].weight.reshape(emb.conv5[0].weight.shape[0], -1), None, rows)
     t = T.edge_bn_max(y5, emb.bn5, None, rows, y5.shape[1], 1)
     if emb.is_global:
-        tt = t[:rows].reshape(B, M, -1)
-        pooled = torch.cat((tt.max(dim=1)[0], tt.mean(dim=1)), -1)                                 # [B, 1024]
+        pooled = T.pool_max_mean(t, B, M, t.shape[1])                                              # [B, 1024] = [max | mean] over the scene
         return T.mlp_forward(emb.out_mlp, pooled, "GELU")
     y = T.mlp_panels(emb.out_mlp, [t], [t.shape[1]], rows, "GELU")
     return T.from_panel(y, rows, emb.out_mlp.out_layer.out_features).reshape(B, M, -1)

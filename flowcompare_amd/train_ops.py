@@ -636,3 +636,33 @@ class ExpmCouplingFn(torch.autograd.Function):
 def expm_coupling(x2, o, cp, rows, d2):
     scal4 = torch.cat((cp.scale.reshape(1), cp.shift.reshape(1), cp.rescale.reshape(1), cp.reshift.reshape(1)))
     return ExpmCouplingFn.apply(x2, o, scal4, rows, d2)
+
+
+class PoolMaxMeanFn(torch.autograd.Function):
+    """[max over a scene's M points | mean] of a panel t [B*M (padded), width] -> [B, 2 width] (DGCNNembedderGlobal, pytorch_gcn.py:178-182)."""
+
+    @staticmethod
+    def forward(ctx, t, B, M, width):
+        L = engine.lib()
+        out = torch.empty(B, 2 * width, dtype=torch.float32, device=t.device)
+        arg = torch.empty(B, width, dtype=torch.int32, device=t.device)
+        with _OnDevice(t.device):
+            engine._check(L.fc_train_pool_fwd_f32(engine._ptr(t), t.shape[1], width, B, M, engine._ptr(out), 2 * width, engine._ptr(arg), engine._stream()))
+        ctx.save_for_backward(arg)
+        ctx.meta = (B, M, width, t.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = engine.lib()
+        (arg,) = ctx.saved_tensors
+        B, M, width, shape = ctx.meta
+        g = g.contiguous()
+        dt = torch.zeros(shape, dtype=torch.float32, device=g.device)
+        with _OnDevice(g.device):
+            engine._check(L.fc_train_pool_bwd_f32(engine._ptr(g), g.shape[1], engine._ptr(arg), width, B, M, engine._ptr(dt), shape[1], engine._stream()))
+        return dt, None, None, None
+
+
+def pool_max_mean(t, B, M, width):
+    return PoolMaxMeanFn.apply(t, B, M, width)

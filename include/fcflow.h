@@ -294,6 +294,10 @@ int fc_train_edge_fwd_f32(const float* P, int32_t ldp, const float* Q, int32_t l
 int fc_train_edge_bwd_prep_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
                                const float* stats, const float* gamma, const float* beta, const uint8_t* arg, const float* g, int32_t ldg, float* t1,
                                float* t2, int32_t ldt, int32_t rows_pad, void* stream);
+/* Pooling of the global embedder (models/pytorch_gcn.py:178-182): out [B, >= 2 width] = [max over the scene's M points | mean],
+ * arg [B, width] = arg-max point; bwd: dt [B*M, lddt]. */
+int fc_train_pool_fwd_f32(const float* t, int32_t ldt, int32_t width, int32_t B, int32_t M, float* out, int32_t ldo, int32_t* arg, void* stream);
+int fc_train_pool_bwd_f32(const float* g, int32_t ldg, const int32_t* arg, int32_t width, int32_t B, int32_t M, float* dt, int32_t lddt, void* stream);
 int fc_train_edge_bwd_gather_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
                                  const float* stats, const float* gamma, const uint8_t* arg, const float* t1, int32_t ldt, const float* dbeta,
                                  const float* dgamma, const int32_t* order, const int32_t* offsets, float* dP, int32_t lddp, void* stream);
