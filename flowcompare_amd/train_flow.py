@@ -74,13 +74,15 @@ def _perm_weight(perm, cfg):
 
 def _actnorm_data_init(an, parts, rows):
     """act_norm.py:27-39, 72-88: on the first training batch shift = mean and log_scale = log(unbiased std + eps) of the layer's input
-    over batch and points.  One-off, so the two reductions are torch ops on the panels.  Like the reference it REPLACES the
+    over batch and points (column statistics by the HIP reduction kernel, fp64 accumulation).  Like the reference it REPLACES the
     Parameter objects (an optimiser built before the first forward therefore keeps updating the old, orphaned tensors and these
     stay at their data-dependent values -- the reference's behaviour, kept on purpose)."""
     with torch.no_grad():
-        xcat = torch.cat([p[:rows, :w] for p, w in parts], -1)
-        an.shift = torch.nn.Parameter(xcat.mean(0, keepdim=True))
-        an.log_scale = torch.nn.Parameter(torch.log(xcat.std(0, keepdim=True) + an.eps))
+        stats = [T.column_stats(p.detach(), w, rows) for p, w in parts]              # HIP reduction; what follows is parameter-sized
+        mean = torch.cat([m for m, _ in stats])
+        var = torch.cat([v for _, v in stats]) * (rows / max(rows - 1, 1))           # unbiased, as tensor.std() in act_norm.py:84-85
+        an.shift = torch.nn.Parameter(mean.reshape(1, -1).clone())
+        an.log_scale = torch.nn.Parameter(torch.log(torch.sqrt(var) + an.eps).reshape(1, -1))
         an.initialized += 1.0
 
 

@@ -666,3 +666,17 @@ class PoolMaxMeanFn(torch.autograd.Function):
 
 def pool_max_mean(t, B, M, width):
     return PoolMaxMeanFn.apply(t, B, M, width)
+
+
+def column_stats(panel, width, rows, eps=0.0):
+    """Per-column mean and BIASED variance of a panel's first `rows` rows and `width` columns (fp64 accumulation on the device, the
+    statistics kernel of the EdgeConv BatchNorm with k = 1): returns (mean [width], var [width]) -- parameter-sized vectors."""
+    L = engine.lib()
+    _check_panel(panel, width)
+    stats = torch.empty(3 * width, dtype=torch.float32, device=panel.device)
+    with _OnDevice(panel.device):
+        nb = L.fc_train_edge_ws_bytes(rows, width)
+        ws = _ws(nb, panel.device)
+        engine._check(L.fc_train_edge_stats_f32(engine._ptr(panel), panel.shape[1], ctypes.c_void_p(0), 0, ctypes.c_void_p(0), rows, 1, width,
+                                                ctypes.c_float(eps), engine._ptr(stats), engine._ptr(ws), ctypes.c_size_t(nb), engine._stream()))
+    return stats[:width], stats[2 * width:]
