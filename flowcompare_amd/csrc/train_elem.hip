@@ -24,15 +24,23 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return s;
 }
 
+// One workgroup per point.  The point's d2 (3K+1) logits are staged through LDS with coalesced 16-byte loads (a thread evaluating one
+// dim reads 3K+1 consecutive floats: straight from HBM that is a 100-byte stride across the wave); 3K+1 is odd, so the per-thread
+// reads from LDS are conflict-free.
 template <int K>
 __global__ __launch_bounds__(256) void spline_train_fwd_kernel(const float* __restrict__ x2, int ldx, const float* __restrict__ params, int ldp,
                                                                float* __restrict__ y2, int ldy, float* __restrict__ ldj, int d2, int d2_pad) {
+    extern __shared__ float sp[];                        // [d2 (3K+1)] rounded up to 4
     __shared__ float red[4];
     const size_t row = blockIdx.x;
+    const int np = d2 * (3 * K + 1), np4 = (np + 3) >> 2;
+    const float4* src = reinterpret_cast<const float4*>(params + row * ldp);          // panel rows are 16-byte aligned, ldp >= round_up(np, 32)
+    for (int i = threadIdx.x; i < np4; i += 256) reinterpret_cast<float4*>(sp)[i] = src[i];
+    __syncthreads();
     float part = 0.f;
     for (int dim = threadIdx.x; dim < d2_pad; dim += 256) {
         float y = 0.f, lad = 0.f;
-        if (dim < d2) rq_spline_elem<K>(x2[row * ldx + dim], params + row * ldp + (size_t)dim * (3 * K + 1), 1, false, y, lad);
+        if (dim < d2) rq_spline_elem<K>(x2[row * ldx + dim], sp + dim * (3 * K + 1), 1, false, y, lad);
         y2[row * ldy + dim] = y;
         part += lad;
     }
@@ -141,20 +149,28 @@ __global__ __launch_bounds__(256) void spline_train_bwd_kernel(const float* __re
                                                                const float* __restrict__ dy2, int lddy, const float* __restrict__ dldj,
                                                                float* __restrict__ dx2, int lddx, float* __restrict__ dparams, int lddp, int d2,
                                                                int d2_pad, int np_pad) {
+    extern __shared__ float sp[];                        // logits in, their gradients out (in place): [round_up(d2 (3K+1), 32)]
     const size_t row = blockIdx.x;
+    const int np = d2 * (3 * K + 1), np4 = (np + 3) >> 2;
+    const float4* src = reinterpret_cast<const float4*>(params + row * ldp);
+    for (int i = threadIdx.x; i < np4; i += 256) reinterpret_cast<float4*>(sp)[i] = src[i];
+    __syncthreads();
     const float gl = dldj[row];
     for (int dim = threadIdx.x; dim < d2_pad; dim += 256) {
         float gx = 0.f;
         if (dim < d2) {
             float gu[3 * K + 1];
-            rq_spline_bwd_elem<K>(x2[row * ldx + dim], params + row * ldp + (size_t)dim * (3 * K + 1), dy2[row * lddy + dim], gl, gx, gu);
-            float* dst = dparams + row * lddp + (size_t)dim * (3 * K + 1);
+            float* u = sp + dim * (3 * K + 1);
+            rq_spline_bwd_elem<K>(x2[row * ldx + dim], u, dy2[row * lddy + dim], gl, gx, gu);
 #pragma unroll
-            for (int i = 0; i < 3 * K + 1; ++i) dst[i] = gu[i];
+            for (int i = 0; i < 3 * K + 1; ++i) u[i] = gu[i];                  // this thread's own logits: nobody else reads them
         }
         dx2[row * lddx + dim] = gx;
     }
-    for (int c = d2 * (3 * K + 1) + threadIdx.x; c < np_pad; c += 256) dparams[row * lddp + c] = 0.f;
+    for (int c = np + threadIdx.x; c < np_pad; c += 256) sp[c] = 0.f;
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(dparams + row * lddp);
+    for (int i = threadIdx.x; i < (np_pad >> 2); i += 256) dst[i] = reinterpret_cast<const float4*>(sp)[i];
 }
 
 // ---------------------------------------------------------------- LayerNorm: one wave per row
@@ -485,14 +501,18 @@ __global__ void expm_train_bwd_kernel(const float* __restrict__ x2, int ldx, con
 template <int K>
 static void spline_fwd_k(const float* x2, int ldx, const float* params, int ldp, float* y2, int ldy, float* ldj, int rows, int d2, hipStream_t s) {
     ProfScope ps("fc::spline_train_fwd_kernel", 0.0, (double)rows * d2 * (3 * K + 3) * 4.0, s);
-    hipLaunchKernelGGL(spline_train_fwd_kernel<K>, dim3(rows), dim3(256), 0, s, x2, ldx, params, ldp, y2, ldy, ldj, d2, round_up(d2, 32));
+    const size_t lds = (size_t)round_up(d2 * (3 * K + 1), 32) * sizeof(float);
+    if (lds > 60 * 1024) throw Error(FC_ERR_UNSUPPORTED, "training spline: more than 15360 logits per point");
+    hipLaunchKernelGGL(spline_train_fwd_kernel<K>, dim3(rows), dim3(256), lds, s, x2, ldx, params, ldp, y2, ldy, ldj, d2, round_up(d2, 32));
     FC_HIP(hipGetLastError());
 }
 template <int K>
 static void spline_bwd_k(const float* x2, int ldx, const float* params, int ldp, const float* dy2, int lddy, const float* dldj, float* dx2, int lddx,
                          float* dparams, int lddp, int rows, int d2, hipStream_t s) {
     ProfScope ps("fc::spline_train_bwd_kernel", 0.0, (double)rows * d2 * (6 * K + 5) * 4.0, s);
-    hipLaunchKernelGGL(spline_train_bwd_kernel<K>, dim3(rows), dim3(256), 0, s, x2, ldx, params, ldp, dy2, lddy, dldj, dx2, lddx, dparams, lddp, d2,
+    const size_t lds = (size_t)round_up(d2 * (3 * K + 1), 32) * sizeof(float);
+    if (lds > 60 * 1024) throw Error(FC_ERR_UNSUPPORTED, "training spline: more than 15360 logits per point");
+    hipLaunchKernelGGL(spline_train_bwd_kernel<K>, dim3(rows), dim3(256), lds, s, x2, ldx, params, ldp, dy2, lddy, dldj, dx2, lddx, dparams, lddp, d2,
                        round_up(d2, 32), round_up(d2 * (3 * K + 1), 32));
     FC_HIP(hipGetLastError());
 }
@@ -507,8 +527,9 @@ extern "C" {
 int fc_train_rqspline_fwd_f32(const float* x2, int32_t ldx, const float* params, int32_t ldp, float* y2, int32_t ldy, float* ldj, int32_t rows,
                               int32_t d2, int32_t K, void* stream) {
     FC_API_BEGIN
-    if (!x2 || !params || !y2 || !ldj || rows < 1 || d2 < 1 || ldx < d2 || ldy < round_up(d2, 32) || ldp < d2 * (3 * K + 1))
-        throw Error(FC_ERR_INVALID, "fc_train_rqspline_fwd_f32: bad argument");
+    if (!x2 || !params || !y2 || !ldj || rows < 1 || d2 < 1 || ldx < d2 || ldy < round_up(d2, 32) || ldp < round_up(d2 * (3 * K + 1), 4) || ldp % 4 != 0 ||
+        ((uintptr_t)params & 15))
+        throw Error(FC_ERR_INVALID, "fc_train_rqspline_fwd_f32: bad argument (params: 16-byte aligned rows, pitch a multiple of 4)");
     hipStream_t s = (hipStream_t)stream;
     switch (K) {
         case 4: spline_fwd_k<4>(x2, ldx, params, ldp, y2, ldy, ldj, rows, d2, s); break;
@@ -523,8 +544,8 @@ int fc_train_rqspline_bwd_f32(const float* x2, int32_t ldx, const float* params,
                               float* dx2, int32_t lddx, float* dparams, int32_t lddp, int32_t rows, int32_t d2, int32_t K, void* stream) {
     FC_API_BEGIN
     if (!x2 || !params || !dy2 || !dldj || !dx2 || !dparams || rows < 1 || d2 < 1 || ldx < d2 || lddy < d2 || lddx < round_up(d2, 32) ||
-        ldp < d2 * (3 * K + 1) || lddp < round_up(d2 * (3 * K + 1), 32))
-        throw Error(FC_ERR_INVALID, "fc_train_rqspline_bwd_f32: bad argument");
+        ldp < round_up(d2 * (3 * K + 1), 4) || ldp % 4 != 0 || lddp < round_up(d2 * (3 * K + 1), 32) || lddp % 4 != 0 || (((uintptr_t)params | (uintptr_t)dparams) & 15))
+        throw Error(FC_ERR_INVALID, "fc_train_rqspline_bwd_f32: bad argument (params / dparams: 16-byte aligned rows, pitches multiples of 4)");
     hipStream_t s = (hipStream_t)stream;
     switch (K) {
         case 4: spline_bwd_k<4>(x2, ldx, params, ldp, dy2, lddy, dldj, dx2, lddx, dparams, lddp, rows, d2, s); break;
