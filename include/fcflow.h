@@ -14,6 +14,9 @@
  *     workspaces; all tensors are fp32, contiguous, channels-last [B, points, features].
  *   - weights are handed over as the reference checkpoint's state_dict entries (name, shape, host
  *     pointer); folding / padding / packing for the kernels happens inside create.
+ * ABI history: 1 = forward log-prob engine; 2 = + inverse / sampling, staging and change-map entries, profiler filter;
+ * 3 = + the stateless training primitives fc_train_* (forward AND backward of every node of the path, no handles: parameters stay
+ *     the caller's dense fp32 device tensors because they change every optimiser step).
  */
 #ifndef FCFLOW_H
 #define FCFLOW_H
