@@ -17,6 +17,7 @@ import flowcompare_amd as fa          # noqa: E402
 from flowcompare_amd import engine, train_flow     # noqa: E402
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="c2_dgcnn_attn_spline", help="c2_dgcnn_attn_spline | c4_dgcnn_attn_extra_affine | c1_dgcnn_global_affine")
 ap.add_argument("--layers", type=int, default=115)
 ap.add_argument("--scenes", type=int, default=16)
 ap.add_argument("--points", type=int, default=4096)
@@ -29,7 +30,7 @@ a = ap.parse_args()
 dev = "cuda:0"
 if a.budget_gb >= 0:
     train_flow.ACTIVATION_BUDGET_BYTES = int(a.budget_gb * 2**30)
-cfg = fa.named_config("c2_dgcnn_attn_spline", sample_size=a.points, n_flow_layers=a.layers)
+cfg = fa.named_config(a.config, sample_size=a.points, n_flow_layers=a.layers)
 torch.manual_seed(0)
 md = fa.initialize_flow(cfg, device=dev, mode="test")
 md["flow"].train()
@@ -44,7 +45,8 @@ xyz = torch.rand(B, 2 * N, 3, generator=g) * 2 - 1
 xyz = xyz - xyz.mean(1, keepdim=True)
 xyz = xyz / xyz.norm(dim=-1).amax(1)[:, None, None]
 pts = torch.cat((xyz, torch.rand(B, 2 * N, 3, generator=g)), -1).to(dev)
-batch = (pts[:, :N].contiguous(), pts[:, N:].contiguous(), None)
+extra = torch.rand(B, 1, generator=g).to(dev) * 15 if cfg["extra_z_value_context"] else None
+batch = (pts[:, :N].contiguous(), pts[:, N:].contiguous(), extra)
 eps = [torch.randn(B, N, 294, generator=g).to(dev)]
 opt = torch.optim.Adam(md["parameters"], lr=1e-5)
 lib = engine.lib()
@@ -69,5 +71,5 @@ if a.profile:
     print(buf.value.decode())
 ms = 1e3 * sum(times) / len(times)
 print(json.dumps({"metric": "training step (forward + backward + Adam), points/s", "value": B * N / (ms / 1e3), "ms_per_step": ms, "layers": a.layers,
-                  "scenes": B, "points": N, "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30,
+                  "config": a.config, "scenes": B, "points": N, "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30,
                   "embedder": "frozen (eval)" if a.frozen_embedder else "trained (BatchNorm batch statistics)"}))
