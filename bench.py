@@ -99,6 +99,10 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=4096, help="target points = context points per scene")
     ap.add_argument("--layers", type=int, default=None, help="override n_flow_layers (INVALID as a headline number)")
+    ap.add_argument("--weights", choices=("conditioned", "module"), default="conditioned",
+                    help="conditioned (default): module init + flowcompare_amd.conditioning.condition_flow (near-identity coupling output layers, "
+                         "LinearLU mixing, ActNorm first-batch statistics) -- the state the full-depth parity tests gate at 1e-4 bpd; "
+                         "module: the constructors' init as it is (ill-conditioned at 115 layers: diagnostic only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: leave the in-library HIP-event profiler off in the timed region")
     ap.add_argument("--knob", action="append", default=[], help="K=V tuning knob for same-box A/B runs (fc_debug_set); not for headline numbers")
@@ -133,6 +137,16 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):          # the reference API prints its parameter count: stdout carries only the JSON line
         md = fa.initialize_flow(cfg, device=dev, mode="test")
     B, N = args.batch, args.points
+    if args.weights == "conditioned":
+        # the same two conditioning scenes on every rank -> identical weights on every rank (kernel work does not depend on the values)
+        from flowcompare_amd.conditioning import condition_flow
+        c0, c1, cx, cg = synth_pairs(2, N, N, 999, dev)
+        ceps = [torch.randn(2, N, cfg["latent_dim"] - cfg["input_dim"], generator=cg).to(dev)]
+        t_c = time.perf_counter()
+        condition_flow(md, cfg, (c0, c1, cx if cfg["extra_z_value_context"] else None), eps=ceps)
+        torch.cuda.synchronize()
+        log(f"rank {rank}: weights conditioned in {time.perf_counter() - t_c:.1f} s")
+        del c0, c1, cx, ceps
     e0, e1, extra, g = synth_pairs(B, N, N, 1000 + rank, dev)   # every rank owns different scenes
     batch = (e0, e1, extra if cfg["extra_z_value_context"] else None)
     eps = [torch.randn(B, N, cfg["latent_dim"] - cfg["input_dim"], generator=g).to(dev)]
@@ -210,7 +224,9 @@ def main():
                 achieved, peak = useful, PEAK_F32_MATRIX_TFLOPS
                 note = "fp32-input MFMA (v_mfma_f32_32x32x2_f32) against its dense peak 157.3 TFLOP/s"
             roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                    "frac": achieved / peak, "traffic": None, "useful_fp32_equivalent_tflops": useful, "peak_source": "MI355X_MICROARCH.md; " + note}
+                    "frac": achieved / peak, "frac_algorithmic": useful / peak, "traffic": None, "useful_fp32_equivalent_tflops": useful,
+                    "frac_note": "frac = MFMA FLOPs issued / peak (issue rate); frac_algorithmic = algorithmic fp32-equivalent FLOPs (SURVEY.md 8d) / the same peak",
+                    "peak_source": "MI355X_MICROARCH.md; " + note}
         else:
             achieved = dom["bytes"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -230,7 +246,7 @@ def main():
         out = {
             "metric": "nats/sec (forward log-prob) on 4096-pt coloured pairs", "value": value, "unit": "nats/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16x2 split (fp32-equivalent operands, f32 accumulate) / f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16x2 split (fp32-equivalent operands, f32 accumulate) / f32", "data": "synthetic" + (" (conditioned random-init weights, flowcompare_amd/conditioning.py)" if args.weights == "conditioned" else " (module-init weights)"),
             "config": {"workload": f"{args.config}: batch {B} scenes/GPU x {N} target + {N} context points, "
                                    f"{cfg['n_flow_layers']} flow layers ({cfg['flow_type']}), embedder {cfg['input_embedder']}",
                        "global_batch": world * B, "points_per_scene": N, "parallelism": f"scene-sharded x{world}, no data-path collective"},

@@ -129,6 +129,11 @@ def initialize_flow(config, device="cuda", mode="train"):
     if mode == "train":
         input_embedder.train()
         flow.train()
+        if isinstance(input_embedder, M.PointNet2SSGSeg) and not M.PointNet2SSGSeg.TRAINABLE:
+            # the PAConv embedder has inference kernels only: it stays frozen in eval() mode (running-statistics BatchNorm) and
+            # receives no gradient; the flow on top of it trains
+            input_embedder.eval()
+            input_embedder.requires_grad_(False)
     else:
         input_embedder.eval()
         flow.eval()

@@ -457,6 +457,7 @@ class PointNet2FPModule(_Container):
 class PointNet2SSGSeg(nn.Module):
     """PAConv context embedder: 4 set-abstraction levels (FPS to n/4, 32-NN grouping, 3 PAConv layers, max) + 4 feature
     propagation levels (3-NN inverse-distance interpolation, skip concat, shared MLP) + head MLP."""
+    TRAINABLE = False      # no backward kernels for this embedder: initialize_flow(mode='train') keeps it frozen in eval() mode
 
     def __init__(self, c=3, k=13, use_xyz=True, out_mlp_dims=(512, 512, 512), args=None):
         super().__init__()

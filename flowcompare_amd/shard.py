@@ -53,8 +53,9 @@ def gather_log_prob(log_prob_local, batch_size, group=None):
 def sharded_inner_loop(batch, models_dict, config, eps=None, group=None):
     """inner_loop over this rank's shard of a GLOBAL batch; returns (global loss, local log_prob, global bpd)."""
     from .model_initialization import inner_loop
-    local = shard_batch(batch)
-    lo, hi = shard_bounds(batch[0].shape[0], dist.get_rank(group), dist.get_world_size(group))
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    local = shard_batch(batch, rank, world)
+    lo, hi = shard_bounds(batch[0].shape[0], rank, world)
     eps_local = None if eps is None else [e[lo:hi] for e in eps]
     _, lp, _ = inner_loop(local, models_dict, config, eps=eps_local)
     loss, bpd = global_loss_bpd(lp, config["input_dim"], group)
@@ -65,19 +66,28 @@ def sharded_inner_loop(batch, models_dict, config, eps=None, group=None):
 class GradientReducer:
     """Bucketed SUM all-reduce of parameter gradients, overlapped with backward (one process per GPU; "nccl" = RCCL over xGMI).
 
-    Buckets are filled in REVERSE parameter order: the flow's layers finish their backward last-to-first, so a bucket's all-reduce
-    starts as soon as its last gradient has been accumulated (post-accumulate-grad hooks) while earlier layers are still being
-    differentiated.  xGMI is point-to-point (ring collectives are per-link bound), so buckets are large: 32 MB by default, i.e.
-    about 45 collectives for the 369 M fp32 gradients of the spline flow.  The reduction is a SUM: each rank differentiates
-    -sum(log_prob_local) / n_global_points (`local_loss`), so the summed gradients are those of the global mean loss exactly,
-    also for uneven shards -- what nn.DataParallel (model_initialization.py:186-188) computes by gathering outputs on one device.
-    """
+    Layout: every bucket owns ONE pre-allocated flat buffer and each parameter's `.grad` IS a view into it, so autograd accumulates
+    straight into the collective's send/receive buffer: no flatten (`torch.cat`) before the all-reduce, no copy back after it, no
+    second copy of the gradients in memory.  Buckets are filled in REVERSE parameter order: the flow's layers finish their backward
+    last-to-first, so a bucket's all-reduce starts as soon as its last gradient has been accumulated (post-accumulate-grad hooks) while
+    earlier layers are still being differentiated; the collective runs on the process group's own stream (ProcessGroupNCCL orders it
+    behind the kernels already queued on the compute stream and `finish()` makes the compute stream wait for it).  xGMI is
+    point-to-point (ring collectives are per-link bound), so buckets are large: 32 MB by default, i.e. about 45 collectives for the
+    369 M fp32 gradients of the spline flow.  The reduction is a SUM: each rank differentiates -sum(log_prob_local) / n_global_points
+    (`local_loss`), so the summed gradients are those of the global mean loss exactly, also for uneven shards -- what nn.DataParallel
+    (model_initialization.py:186-188) computes by gathering outputs on one device.
+
+    grad=None semantics: a parameter that received no gradient on ANY rank gets `.grad = None` back after `finish()` (one extra
+    all-reduce of a presence mask per step), so clip_grad_norm_ / Adam skip it exactly as they do in the single-process loop."""
 
     def __init__(self, params, bucket_bytes=32 << 20, group=None):
         self.group = group
         self.params = [p for p in params if p.requires_grad]
         self.buckets, cur, size = [], [], 0
+        dtype = self.params[0].dtype
         for p in reversed(self.params):
+            if p.dtype != dtype:
+                raise RuntimeError("GradientReducer: all parameters must share one dtype")
             cur.append(p)
             size += p.numel() * p.element_size()
             if size >= bucket_bytes:
@@ -85,46 +95,84 @@ class GradientReducer:
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
+        self.flat, self.views = [], {}
+        for b in self.buckets:
+            flat = torch.zeros(sum(p.numel() for p in b), dtype=dtype, device=b[0].device)
+            off = 0
+            for p in b:
+                self.views[id(p)] = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self.flat.append(flat)
         self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self.index_of = {id(p): j for j, p in enumerate(self.params)}
         self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self.zero_grad()
+
+    def zero_grad(self):
+        """Start of a step: zero the flat buffers and (re-)attach every parameter's .grad to its view."""
+        for flat in self.flat:
+            flat.zero_()
+        for p in self.params:
+            p.grad = self.views[id(p)]
         self.reset()
 
     def reset(self):
         self.pending = [len(b) for b in self.buckets]
         self.inflight = [None] * len(self.buckets)
+        self.present = [0.0] * len(self.params)
 
     def _launch(self, i):
-        b = self.buckets[i]
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in b])
-        work = dist.all_reduce(flat, group=self.group, async_op=True)
-        self.inflight[i] = (flat, work)
+        self.inflight[i] = dist.all_reduce(self.flat[i], group=self.group, async_op=True)
 
     def _on_grad(self, p):
+        if p.grad is None or p.grad.data_ptr() != self.views[id(p)].data_ptr():
+            # .grad was detached from its view (e.g. optimizer.zero_grad(set_to_none=True) between steps): fold it back in
+            v = self.views[id(p)]
+            if p.grad is not None:
+                v.copy_(p.grad)
+            p.grad = v
+        self.present[self.index_of[id(p)]] = 1.0
         i = self.bucket_of[id(p)]
         self.pending[i] -= 1
         if self.pending[i] == 0:
             self._launch(i)
 
     def finish(self):
-        """Waits for every bucket (launching those whose parameters received no gradient this step, as zeros, so that all ranks
-        issue the same collectives) and writes the summed gradients back."""
-        for i, b in enumerate(self.buckets):
+        """Waits for every bucket (launching those whose parameters received no gradient this step, as zeros, so that all ranks issue
+        the same collectives); afterwards every .grad view holds the sum over ranks, and parameters without a gradient on any rank have
+        .grad = None again."""
+        for i in range(len(self.buckets)):
             if self.inflight[i] is None:
                 self._launch(i)
-            flat, work = self.inflight[i]
-            work.wait()
-            off = 0
-            for p in b:
-                n = p.numel()
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                p.grad.copy_(flat[off:off + n].view_as(p))
-                off += n
+        mask = torch.tensor(self.present, dtype=torch.float32).to(self.flat[0].device)
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+        for w in self.inflight:
+            w.wait()
+        mask = mask.cpu()
+        for p, m in zip(self.params, mask.tolist()):
+            if m == 0.0:
+                p.grad = None
         self.reset()
 
     def remove(self):
         for h in self.hooks:
             h.remove()
+
+
+def sync_batchnorm_buffers(module, group=None):
+    """Train-mode BatchNorm running statistics are per shard, as in the reference's nn.DataParallel (no SyncBN): every
+    rank updates them from its own scenes.  Averaging them over the ranks after a step keeps the replicas' eval-mode behaviour and
+    checkpoints identical (a conscious deviation: DataParallel keeps replica 0's).  Parameter-sized; one all-reduce."""
+    bufs = [b for n, b in module.named_buffers() if n.endswith(("running_mean", "running_var")) and b.is_floating_point()]
+    if not bufs or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([b.reshape(-1).to(torch.float32) for b in bufs])
+    dist.all_reduce(flat, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for b in bufs:
+        b.copy_(flat[off:off + b.numel()].view_as(b))
+        off += b.numel()
 
 
 def local_loss(log_prob_local, n_global_points):
@@ -135,8 +183,15 @@ def local_loss(log_prob_local, n_global_points):
 def sharded_training_step(batch, models_dict, config, reducer, optimizer=None, eps=None, grad_clip=None, group=None):
     """train.py:108-120 over a GLOBAL batch sharded by scenes: every rank differentiates its scenes through the HIP training path,
     gradients are summed by `reducer` (bucketed, overlapped with backward), then clip_grad_norm_ / optimizer.step() run identically
-    on every rank.  Returns (global loss, local log_prob, global bpd, grad_norm)."""
+    on every rank.  Returns (global loss, local log_prob, global bpd, grad_norm).
+
+    First batch: ActNorm's data-dependent initialisation (act_norm.py:27-39) takes the statistics of the GLOBAL batch (column sums
+    all-reduced over the group) and writes them IN PLACE, so every rank holds the same ActNorm weights and the reducer / optimizer keep
+    pointing at live parameters (the reference replaces the Parameter objects, which orphans them from an optimizer built earlier; with
+    one replica per rank that would also leave the replicas with different models).  BatchNorm running statistics are averaged over the
+    ranks after the step (`sync_batchnorm_buffers`)."""
     from .model_initialization import inner_loop
+    from . import train_flow
     from . import train_ops as T
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_bounds(batch[0].shape[0], rank, world)
@@ -144,11 +199,13 @@ def sharded_training_step(batch, models_dict, config, reducer, optimizer=None, e
     eps_local = None if eps is None else [e[lo:hi] for e in eps]
     n_global = batch[1].shape[0] * batch[1].shape[1]
     params = reducer.params
-    for fp16 in (True, False):
-        for p in params:
-            p.grad = None
-        reducer.reset()
-        with T.step_guard(fp16=fp16, device=local[1].device) as guard:
+    attempts = train_flow.step_attempts(models_dict)
+    snap = train_flow.snapshot_step_state(models_dict)
+    for k, fp16 in enumerate(attempts):
+        if k:
+            train_flow.restore_step_state(models_dict, snap)
+        reducer.zero_grad()
+        with T.step_guard(fp16=fp16, device=local[1].device) as guard, train_flow.actnorm_init_mode(in_place=True, group=group or True):
             _, lp, _ = inner_loop(local, models_dict, config, eps=eps_local)
             local_loss(lp, n_global).backward()
             over = torch.tensor([1.0 if guard.overflowed() else 0.0], device=lp.device)
@@ -156,10 +213,10 @@ def sharded_training_step(batch, models_dict, config, reducer, optimizer=None, e
         dist.all_reduce(over, group=group)                   # every rank repeats the step if ANY rank left the fp16 range
         if over.item() == 0.0:
             break
+    sync_batchnorm_buffers(models_dict["input_embedder"], group)
     loss, bpd = global_loss_bpd(lp.detach(), config["input_dim"], group)
     clip = config.get("grad_clip_val") if grad_clip is None else grad_clip
     norm = torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], max_norm=clip if clip else float("inf"))
     if optimizer is not None:
         optimizer.step()
-        optimizer.zero_grad(set_to_none=True)
     return loss, lp.detach(), bpd, norm

@@ -72,17 +72,58 @@ def _perm_weight(perm, cfg):
     raise NotImplementedError(f"training path: permuter {type(perm).__name__}")
 
 
+class actnorm_init_mode:
+    """How the first-batch ActNorm initialisation (act_norm.py:27-39) writes its statistics while this context is active.
+
+    in_place=False (default outside the context): like the reference, `shift` / `log_scale` are REPLACED by new Parameter objects.
+    in_place=True: the existing Parameters are overwritten (`.copy_`), so optimisers, gradient reducers and `models_dict['parameters']`
+    keep pointing at live tensors -- what the sharded training step and `conditioning.condition_flow` need.
+    group: a torch.distributed process group (or True for the default group): column sums, sums of squares and row counts are
+    all-reduced first, so every rank lands on the statistics of the GLOBAL batch -- bit-identical ActNorm weights on all ranks,
+    equal to what one process computes on the whole batch."""
+    current = (False, None)
+
+    def __init__(self, in_place=True, group=None):
+        self.mode = (bool(in_place), group)
+
+    def __enter__(self):
+        self.prev, actnorm_init_mode.current = actnorm_init_mode.current, self.mode
+        return self
+
+    def __exit__(self, *a):
+        actnorm_init_mode.current = self.prev
+
+
 def _actnorm_data_init(an, parts, rows):
     """act_norm.py:27-39, 72-88: on the first training batch shift = mean and log_scale = log(unbiased std + eps) of the layer's input
-    over batch and points (column statistics by the HIP reduction kernel, fp64 accumulation).  Like the reference it REPLACES the
-    Parameter objects (an optimiser built before the first forward therefore keeps updating the old, orphaned tensors and these
-    stay at their data-dependent values -- the reference's behaviour, kept on purpose)."""
+    over batch and points (column statistics by the HIP reduction kernel, fp64 accumulation).  By default, like the reference, it
+    REPLACES the Parameter objects (an optimiser built before the first forward therefore keeps updating the old, orphaned tensors and
+    these stay at their data-dependent values -- the reference's behaviour, kept on purpose); `actnorm_init_mode` switches to in-place
+    writes and to statistics of the global batch of a process group."""
+    in_place, group = actnorm_init_mode.current
     with torch.no_grad():
         stats = [T.column_stats(p.detach(), w, rows) for p, w in parts]              # HIP reduction; what follows is parameter-sized
-        mean = torch.cat([m for m, _ in stats])
-        var = torch.cat([v for _, v in stats]) * (rows / max(rows - 1, 1))           # unbiased, as tensor.std() in act_norm.py:84-85
-        an.shift = torch.nn.Parameter(mean.reshape(1, -1).clone())
-        an.log_scale = torch.nn.Parameter(torch.log(torch.sqrt(var) + an.eps).reshape(1, -1))
+        mean = torch.cat([m for m, _ in stats]).double()
+        var = torch.cat([v for _, v in stats]).double()                              # biased
+        n = float(rows)
+        if group is not None:
+            import torch.distributed as dist
+            g = None if group is True else group
+            acc = torch.cat((mean * n, (var + mean * mean) * n, torch.tensor([n], dtype=torch.float64, device=mean.device)))
+            dist.all_reduce(acc, group=g)
+            width = mean.numel()
+            n = float(acc[-1].item())
+            mean = acc[:width] / n
+            var = (acc[width:2 * width] / n - mean * mean).clamp_min(0.0)
+        var = var * (n / max(n - 1.0, 1.0))                                          # unbiased, as tensor.std() in act_norm.py:84-85
+        shift = mean.to(torch.float32).reshape(1, -1)
+        log_scale = torch.log(torch.sqrt(var).to(torch.float32) + an.eps).reshape(1, -1)
+        if in_place:
+            an.shift.copy_(shift)
+            an.log_scale.copy_(log_scale)
+        else:
+            an.shift = torch.nn.Parameter(shift.clone())
+            an.log_scale = torch.nn.Parameter(log_scale)
         an.initialized += 1.0
 
 
@@ -284,19 +325,72 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
     return logp[:rows].reshape(B, N)
 
 
+def _stateful_modules(models_dict):
+    actnorms = [m for m in models_dict["flow"].modules() if isinstance(m, M.ActNormBijectionCloud)]
+    bns = [m for m in models_dict["input_embedder"].modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    return actnorms, bns
+
+
+def step_attempts(models_dict):
+    """Which arithmetic a training step tries, in order.  Normally the split-fp16 loops first, then -- if any operand left the fp16
+    range -- the fp32-input loops.  A step in which an ActNorm layer still takes its first-batch statistics runs on the fp32-input loops
+    straight away: that step's side effect (the data-dependent initialisation, act_norm.py:27-39) must come from in-range arithmetic."""
+    actnorms, _ = _stateful_modules(models_dict)
+    if actnorms and models_dict["flow"].training:
+        flags = torch.cat([m.initialized.reshape(1).to(torch.float32) for m in actnorms])
+        if bool((flags == 0).any().item()):
+            return (False,)
+    return (True, False)
+
+
+def snapshot_step_state(models_dict):
+    """What a forward pass in train() mode changes besides gradients: ActNorm `initialized` flags (+ the statistics written on the first
+    batch) and the BatchNorm running statistics of the embedder.  Parameter-sized."""
+    actnorms, bns = _stateful_modules(models_dict)
+    return ([(m, m.shift, m.log_scale, m.shift.detach().clone(), m.log_scale.detach().clone(), m.initialized.clone()) for m in actnorms],
+            [(m, None if m.running_mean is None else m.running_mean.clone(), None if m.running_var is None else m.running_var.clone(),
+              None if m.num_batches_tracked is None else m.num_batches_tracked.clone()) for m in bns])
+
+
+def restore_step_state(models_dict, snap):
+    """Undo the side effects of a rejected attempt (fcflow.h: results are invalid once the range flag is set) before the step is
+    repeated: the BatchNorm running statistics would otherwise be updated twice -- or poisoned by an out-of-range activation -- and a
+    first-batch ActNorm initialisation would keep statistics of invalid activations."""
+    with torch.no_grad():
+        for m, shift_p, ls_p, shift_v, ls_v, init in snap[0]:
+            if m.shift is not shift_p:                 # replaced by the reference-style initialisation: put the old Parameters back
+                m.shift, m.log_scale = shift_p, ls_p
+            m.shift.copy_(shift_v)
+            m.log_scale.copy_(ls_v)
+            m.initialized.copy_(init)
+        for m, rm, rv, nb in snap[1]:
+            if rm is not None:
+                m.running_mean.copy_(rm)
+                m.running_var.copy_(rv)
+            if nb is not None:
+                m.num_batches_tracked.copy_(nb)
+
+
 def training_step(batch, models_dict, config, optimizer=None, eps=None, grad_clip=None):
     """One optimisation step as train.py:108-120 runs it: inner_loop -> loss.backward() -> clip_grad_norm_ -> optimizer.step().
     The flow must be in train() mode (or the inputs require grad) so that Flow.log_prob takes the differentiable HIP path; a DGCNN
-    context embedder in train() mode is differentiated too (train_embed.py, BatchNorm batch statistics); in eval() mode -- and the
-    PAConv embedder always -- it runs its inference kernels and receives no gradient.
+    context embedder in train() mode is differentiated too (train_embed.py, BatchNorm batch statistics); in eval() mode it runs its
+    inference kernels and receives no gradient.
     Range guard: the step runs on the split-fp16 loops first and is repeated on the fp32-input loops if any operand left the fp16
-    range.  Returns (loss, log_prob, bpd, grad_norm)."""
+    range; the rejected attempt's side effects (BatchNorm running statistics, ActNorm first-batch statistics) are rolled back first and
+    every gradient -- also of Parameters an ActNorm initialisation created -- is dropped.  Returns (loss, log_prob, bpd, grad_norm)."""
     from .model_initialization import inner_loop
     params = [p for p in models_dict["parameters"] if p.requires_grad]
     device = batch[1].device
-    for fp16 in (True, False):
+    snap = snapshot_step_state(models_dict)
+    for k, fp16 in enumerate(step_attempts(models_dict)):
+        if k:
+            restore_step_state(models_dict, snap)
         for p in params:
             p.grad = None
+        for mod in (models_dict["flow"], models_dict["input_embedder"]):
+            for p in mod.parameters():
+                p.grad = None
         with T.step_guard(fp16=fp16, device=device) as guard:
             loss, log_prob, bpd = inner_loop(batch, models_dict, config, eps=eps)
             loss.backward()

@@ -443,6 +443,27 @@ def flow_log_prob(cfg, sd, x, ctx, extra=None, eps=(), record=None):
     return lp + std_normal_log_prob(x)
 
 
+def spline_domain_margin(cfg, record):
+    """Test helper for full-depth parity: per point, the smallest | |x2| - 3 | any RationalQuadraticSplineCoupling input of a forward
+    pass came to; `record` is the list flow_log_prob(..., record=[]) filled (latent and log-det after every transform).
+    The reference's spline is the identity with log-det 0 outside [-3, 3] but has derivative softplus(-1e-3) + 1e-3 = 0.6936 at the
+    boundary knots (models/spline_coupling.py:43-45, 35-48), so log p jumps by 0.366 nats when an input crosses +-3: a point whose
+    trajectory passes within rounding distance of the boundary may legitimately land on either side in fp32 (the reference's own fp32
+    run does), exactly like a k-NN near-tie.  Returns [B, N] (inf when the flow has no spline coupling)."""
+    margin = torch.full(record[0][0].shape[:-1], float("inf"), dtype=record[0][0].dtype)
+    if cfg["flow_type"] != "RationalQuadraticSplineCoupling":
+        return margin
+    if cfg["latent_dim"] != cfg["cif_latent_dim"]:
+        raise NotImplementedError("spline_domain_margin: plain PreConditionApplier stacks only")
+    d1 = cfg["latent_dim"] // 2
+    prev = None
+    for (kind, _idx), (x, _l) in zip(_layout(cfg), record):
+        if kind == "block" and prev is not None:
+            margin = torch.minimum(margin, (prev[..., d1:].abs() - 3.0).abs().min(-1)[0])
+        prev = x
+    return margin
+
+
 def flow_inverse(cfg, sd, z, ctx, extra=None, eps=()):
     """models/transform.py:79-84 from a given latent z (the draw from sample_dist is the caller's)."""
     it = iter(eps)

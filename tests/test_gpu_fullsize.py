@@ -1,10 +1,14 @@
 """Parity at BASELINE.json's full size (C2: 16 scenes x 4096 target + 4096 context points, 115 spline layers), where the
-oracle cannot run the whole batch in test time: size-independent properties of the domain plus the oracle on ONE full scene.
+oracle cannot run the whole batch in test time: size-independent properties of the domain plus the oracle on rows of ONE full scene.
+
+Weights: module-initialised under a fixed seed, then conditioned (flowcompare_amd/conditioning.py: near-identity coupling output
+layers, LinearLU mixing, ActNorm first-batch statistics) so that the 115-layer stack is as well conditioned as a checkpoint and the
+golden-fixture gates apply at full depth.
 
   * determinism: two runs are bit-identical;
   * scene independence: a 2-scene sub-batch reproduces its rows of the 16-scene batch bit for bit, so
-  * the pinned oracle on 512 target points of scene 0 (full context) checks those rows of the 16-scene run; at 115 layers
-    with module-initialised weights the gate is relative to the reference arithmetic's own fp32-vs-fp64 gap;
+  * the pinned oracle in fp64 on 512 target points of scene 0 (full 4096-point context) checks those rows of the 16-scene run with
+    the gates of the golden fixtures: |bpd - bpd_fp64| < 1e-4, per point < 2e-3, mean < 3e-4;
   * invertibility: inverse(latent(x)) returns x (the augmented dims are dropped by the inverse, models/augmenter semantics).
 """
 import time
@@ -14,28 +18,17 @@ import torch
 
 import flowcompare_amd as fa
 from oracle import flow_oracle as O
+from fullsize_util import build_conditioned, check_rows_against_fp64, oracle_flow_rows, state_dicts, synth_pairs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 B, NPTS = 16, 4096
 
 
-def _pairs(seed):
-    g = torch.Generator().manual_seed(seed)
-    xyz = torch.rand(B, 2 * NPTS, 3, generator=g) * 2 - 1
-    xyz = xyz - xyz.mean(1, keepdim=True)
-    xyz = xyz / xyz.norm(dim=-1).amax(1)[:, None, None]
-    pts = torch.cat((xyz, torch.rand(B, 2 * NPTS, 3, generator=g)), -1)
-    eps = torch.randn(B, NPTS, 294, generator=g)
-    return pts[:, :NPTS].contiguous(), pts[:, NPTS:].contiguous(), eps
-
-
 @pytest.fixture(scope="module")
 def c2():
-    cfg = fa.named_config("c2_dgcnn_attn_spline", sample_size=NPTS)
-    torch.manual_seed(11)
-    md = fa.initialize_flow(cfg, device=DEV, mode="test")
-    e0, e1, eps = _pairs(12)
+    cfg, md = build_conditioned("c2_dgcnn_attn_spline", NPTS, DEV)
+    e0, e1, _, eps = synth_pairs(B, NPTS, NPTS, 12)
     return cfg, md, e0, e1, eps
 
 
@@ -51,32 +44,33 @@ def test_full_size_determinism_and_scene_independence(c2):
     assert torch.equal(lps, lp1[sub])
 
 
-def test_full_size_scene_is_as_close_to_fp64_as_the_reference_arithmetic(c2):
+def test_full_size_rows_match_fp64_oracle_at_golden_gates(c2):
     """Target points do not interact (each attends to the context only), so the oracle on the first 512 target points of scene 0
-    against the FULL 4096-point context checks those rows of the 16-scene run.  With module-initialised weights 115 layers are
-    far from fp64 in fp32 itself: the reference's arithmetic (the oracle in fp32) sits ~26 nats per point away from its fp64
-    run (L = 8: 2e-4, L = 32: 4e-2 on a few points; profiles/micro/c2_scan.py), so the gates are relative to that gap: the HIP
-    path must be as close to fp64 as eager fp32 PyTorch is, and much closer to eager fp32 PyTorch than fp64 is."""
+    against the FULL 4096-point context checks those rows of the 16-scene, 115-layer run -- at the tolerance north_star states:
+    bpd within 1e-4 of the fp64 oracle, every row within 2e-3 (rows on the spline's +-3 boundary: near-tie rule, fullsize_util).
+    The oracle's own fp32-vs-fp64 gap on the same rows is printed beside it."""
     cfg, md, e0, e1, eps = c2
     n = 512
     _, lp, _ = fa.inner_loop((e0.to(DEV), e1.to(DEV), None), md, cfg, eps=[eps.to(DEV)])
-    lp = lp[0, :n].cpu().double()
-    c = dict(cfg)
-    c["sample_size"] = n
-    sd_f = {k: v.cpu() for k, v in md["flow"].state_dict().items()}
-    sd_e = {k: v.cpu() for k, v in md["input_embedder"].state_dict().items()}
+    ctx = md["input_embedder"](e0[:1].to(DEV)).cpu()
     t0 = time.time()
+    lp64, margin = oracle_flow_rows(cfg, md, ctx, e1[:1, :n], None, [eps[:1, :n]], torch.float64)
+    lp32, _ = oracle_flow_rows(cfg, md, ctx, e1[:1, :n], None, [eps[:1, :n]], torch.float32)
+    print(f"oracle: {time.time() - t0:.0f} s of host time")
+    check_rows_against_fp64("C2 16 x 4096 x 115 spline layers, scene 0 rows 0..511", lp[0, :n].cpu(), lp64, lp32, margin)
+
+
+def test_full_size_embedder_matches_fp64_oracle(c2):
+    """DGCNN context embedder on one full 4096-point scene against the oracle in fp64 (k-NN near-ties can flip a neighbour, which moves
+    single rows: judged by quantile and by the worst row)."""
+    cfg, md, e0, e1, eps = c2
+    emb = md["input_embedder"](e0[:1].to(DEV)).cpu().double()
+    _, sd_e = state_dicts(md, torch.float64)
     with torch.no_grad():
-        _, lp32, _ = O.inner_loop(c, sd_f, sd_e, (e0[:1], e1[:1, :n], None), [eps[:1, :n]])
-        _, lp64, _ = O.inner_loop(c, {k: v.double() for k, v in sd_f.items()}, {k: v.double() for k, v in sd_e.items()},
-                                  (e0[:1].double(), e1[:1, :n].double(), None), [eps[:1, :n].double()])
-    d_hip, d_ref, d_32 = (lp - lp64[0]).abs(), (lp32[0].double() - lp64[0]).abs(), (lp - lp32[0].double()).abs()
-    print(f"full-size scene 0, {n} targets x 4096 context, 115 layers ({time.time() - t0:.0f} s of host time): "
-          f"|hip - fp64| max {d_hip.max():.2e} mean {d_hip.mean():.2e};  |oracle fp32 - fp64| max {d_ref.max():.2e} mean {d_ref.mean():.2e}; "
-          f"|hip - oracle fp32| max {d_32.max():.2e} mean {d_32.mean():.2e}")
-    assert d_hip.mean().item() <= 1.1 * d_ref.mean().item() + 3e-4
-    assert d_hip.max().item() <= 1.1 * d_ref.max().item() + 2e-3
-    assert d_32.mean().item() <= 0.05 * d_ref.mean().item() + 3e-4     # far closer to the fp32 reference arithmetic than fp64 is
+        ref = O.context_embed(cfg, sd_e, e0[:1].double())
+    d = (emb - ref).abs().amax(-1)[0]
+    print(f"C2 embedder, 4096 points: per-row max |hip - fp64| median {d.median():.2e} q99 {d.quantile(0.99):.2e} max {d.max():.2e}")
+    assert d.quantile(0.99).item() < 2e-5 and d.max().item() < 5e-3
 
 
 def test_full_size_inverse_round_trip(c2):
