@@ -16,8 +16,15 @@ flow is in when training starts in earnest:
      initialisation (models/act_norm.py:27-39, 72-88), computed by the HIP training kernels -- and is marked initialised.
 
 The result is an ordinary state_dict (oracle and HIP engine both consume it): log-probs of a few tens of nats per point, and the
-oracle's fp32-vs-fp64 gap drops to the reference's own noise floor.  Kernel work is unchanged: same shapes, same
-launches, inputs of every spline inside its +-3 domain.
+oracle's fp32-vs-fp64 gap on the logged scalar (bpd) drops to the reference's own noise floor (4.5e-5).  Kernel work is
+unchanged: same shapes, same launches, inputs of every spline inside its +-3 domain.
+
+What conditioning cannot remove (measured with the oracle, profiles/micro/depth_error_trace.py): a 115-layer stack of mixing layers
+is a dynamical system with a positive Lyapunov exponent -- along single rows the fp32-vs-fp64 distance of the latent grows by ~1.04x
+per layer (1e-6 after the first layer, 1e-3 around layer 70) before it decays again, for ANY fp32 arithmetic including the
+reference's own, so the worst of 512 rows sits 5e-3 ... 2e-2 nats from fp64 in eager fp32 PyTorch while the mean over rows (the bpd
+the reference logs) agrees to 5e-5.  The full-depth tests therefore gate the scalar absolutely (1e-4) and the per-row distance
+against the reference arithmetic's own distance on the same rows.
 """
 import math
 
@@ -34,7 +41,7 @@ def _couplings(flow):
             yield t.flow.transform
 
 
-def condition_flow(models_dict, config, batch, eps=None, out_scale=0.1, lu_scale=0.1, seed=0):
+def condition_flow(models_dict, config, batch, eps=None, out_scale=0.1, lu_scale=0.03, seed=0):
     """In place on models_dict['flow'] (HIP device).  `batch` = (extract_0, extract_1, extra_context) as for inner_loop: the batch
     the ActNorm statistics are taken from (the embedder runs as it is, normally in eval mode).  Returns models_dict."""
     from . import train_flow

