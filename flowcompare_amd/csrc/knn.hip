@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ f, i
         int32_t* idxs = s_idx + (wave * KNN_Q + qq) * KNN_CAP;
         if (cnt[qq] > k) { prune_set(vals, idxs, cnt[qq], k, lane); cnt[qq] = k; }
         const int qi = q_base + wave * KNN_Q + qq;
-        if (qi < M && lane < k) idx_out[((size_t)b * M + qi) * k + lane] = idxs[lane];
+        // fewer than k finite candidates (NaN / -inf features, e.g. in a pass whose fp16 range flag is already up and whose results
+        // will be discarded): the open slots get the query itself, never an uninitialised index (the gathers downstream trust them)
+        if (qi < M && lane < k) idx_out[((size_t)b * M + qi) * k + lane] = lane < cnt[qq] ? idxs[lane] : qi;
     }
 }
 

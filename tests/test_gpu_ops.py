@@ -237,3 +237,13 @@ def test_paconv_embedder_matches_reference_golden():
     d = np.abs(emb - fx.a["emb_f64"])
     print(f"paconv embedder: max {d.max():.2e} mean {d.mean():.2e}")
     assert d.max() < 2e-5
+
+
+def test_knn_with_non_finite_features_returns_valid_indices():
+    """A pass whose fp16 range flag is already raised keeps running until the caller discards it: k-NN on NaN / inf features must still
+    hand valid row indices to the gathers downstream (found by tests/test_gpu_train.py::test_training_step_rolls_back_...)."""
+    f = _rand(2, 300, 8, seed=9)
+    f[0] = float("nan")
+    f[1, 7] = float("inf")
+    idx = engine.op_knn(f.to(DEV), 40).cpu().long()
+    assert idx.min() >= 0 and idx.max() < 300

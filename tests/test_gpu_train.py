@@ -716,13 +716,14 @@ def test_training_step_rolls_back_a_rejected_fp16_attempt():
     md["flow"].train()
     md["input_embedder"].train()
     e0, e1, ex = fx.t("extract_0").to(DEV), fx.t("extract_1").to(DEV), fx.t("extra")
-    e1 = e1.clone()
-    e1[0, 0, 0] = 7.0e4                                              # outside the fp16 range: the guard flag rises in the first Linear
-    batch = (e0, e1, None if ex is None else ex.to(DEV))
+    e0 = e0.clone()
+    e0[0, 0, 0] = 7.0e4                                              # a context coordinate outside the fp16 range: the guard flag rises in the
+    batch = (e0, e1, None if ex is None else ex.to(DEV))             # embedder's first EdgeConv product; BatchNorm brings the features back to O(1)
     eps = [e.to(DEV) for e in fx.eps()]
     bn = md["input_embedder"].bn1
     rm0, nb0 = bn.running_mean.clone(), int(bn.num_batches_tracked)
     loss, lp, bpd, norm = TF.training_step(batch, md, cfg, optimizer=None, eps=eps, grad_clip=0)
+    assert torch.isfinite(loss) and torch.isfinite(norm)
     g_retry = {n: p.grad.clone() for n, p in md["flow"].named_parameters() if p.grad is not None}
     rm_retry = bn.running_mean.clone()
     assert int(bn.num_batches_tracked) == nb0 + 1 and torch.isfinite(rm_retry).all()
