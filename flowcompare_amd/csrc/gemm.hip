@@ -52,7 +52,7 @@ struct GemmParams {
 constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN > 128 ? 1 : (BM == 128 && WM * WN == 8) ? 4 : 2)))   // resident waves per SIMD the register budget must allow
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN > 128 ? 1 : (BM == 128 && WM * WN == 8 && VAR != 8) ? 4 : 2)))   // resident waves per SIMD the register budget must allow
 void gemm_f32_kernel(const GemmParams p) {
     constexpr int NT = WM * WN * 64;                       // 4 or 8 waves per workgroup
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -146,7 +146,95 @@ void gemm_f32_kernel(const GemmParams p) {
         }
     }
 
-    if constexpr (VAR >= 3) {
+    if constexpr (VAR == 8) {
+        // ================= split-fp16 main loop on LDS-DMA: BOTH operands arrive as fp16 limb images =================
+        // A is the image its producer's epilogue wrote (e.A16, [rows][K/16][hi 16 | lo' 16]), W the host-packed one (p.W2): the main
+        // loop converts nothing, so global -> LDS is a byte copy and goes through `global_load_lds_dwordx4` (no staging VGPRs, no
+        // ds_write, whose VGPR -> LDS path was half busy in the register-staged loop).  256 x 128 tile on eight waves of 64 x 64 (128
+        // accumulator registers: main + cross-product sets), two waves per SIMD, one workgroup per CU; k tile 32 = two 64-byte
+        // (row, k16) blocks = 128 bytes per LDS row; three LDS stages of 48 KB; ONE raw s_barrier per k tile with a counted vmcnt
+        // wait, so the DMA of tile t+1 stays in flight across the barrier while tile t is multiplied and tile t+2 is issued.
+        //   LDS image: row r = 128 bytes = 8 chunks of 16 B; logical chunk c = 4*(k16 block) + 2*limb + (k half) sits at physical
+        //   chunk c ^ ((r >> 1) & 7): with 128-byte rows two rows share a 256-byte bank row, and ds_read_b128's 16-lane groups
+        //   ({0-3,12-15,20-27}, ...) then hit 16 distinct 16-byte slots.  The DMA writes LDS linearly (wave base + lane * 16), so the
+        //   permutation is applied to the per-lane SOURCE address and again on the read (same involution on both sides).
+        static_assert(BM == 256 && BN == 128 && WM == 4 && WN == 2, "LDS-DMA loop: written for the 256x128 tile on 4x2 waves");
+        constexpr int ROWB8 = 128, STAGE8 = (BM + BN) * ROWB8, NST = 3;
+        constexpr int PPW = STAGE8 / 1024 / (NT / 64);                       // 1-KB DMA pieces per wave and stage: 6
+        typedef __attribute__((address_space(3))) char lds_char;
+        typedef const __attribute__((address_space(1))) char glb_char;
+        char* smc = reinterpret_cast<char*>(smem);
+        const int KT = p.KT;                                                // k32 tiles
+        const size_t rowbytes = (size_t)KT * 128;
+        // piece pc = wave * PPW + i covers stage rows 8 pc .. 8 pc + 7 (rows 0..255: A, 256..383: W); lane l: row 8 pc + (l >> 3), physical chunk l & 7
+        const char* gsrc[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave * PPW + i;
+            const int r = pc * 8 + (lane >> 3);
+            const int cl = (lane & 7) ^ ((r >> 1) & 7);
+            const char* base = pc < BM / 8 ? reinterpret_cast<const char*>(e.A16) + (size_t)(m0 + r) * rowbytes
+                                           : reinterpret_cast<const char*>(p.W2) + (size_t)(n0 + r - BM) * rowbytes;
+            gsrc[i] = base + cl * 16;
+        }
+#define FC_DMA8(KT_, ST_)                                                                                          \
+        {                                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < PPW; ++i)                                                        \
+                __builtin_amdgcn_global_load_lds((glb_char*)(gsrc[i] + (size_t)(KT_) * 128),                       \
+                                                 (lds_char*)(smc + (ST_) * STAGE8 + (wave * PPW + i) * 1024), 16, 0, 0); \
+        }
+        floatx16 corr[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) corr[i][j][r] = 0.f;
+        const int xsw = (li >> 1) & 7;                                      // (row >> 1) & 7 of every row this lane reads (tiles are 32-row aligned)
+        const int a_row = (wr * TM * 32 + li) * ROWB8, b_row = (BM + wc * TN * 32 + li) * ROWB8;
+        FC_DMA8(0, 0)
+        FC_DMA8((1 < KT ? 1 : KT - 1), 1)
+        int st = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");      // this wave's pieces of tile kt have landed (tile kt+1 may fly on)
+            __builtin_amdgcn_s_barrier();                                   // ... and everybody's; everybody is done reading tile kt-1
+            const int kn = kt + 2 < KT ? kt + 2 : KT - 1;                   // (tail: harmless re-loads into a stage nobody reads again)
+            const int sn = st >= 1 ? st - 1 : 2;                            // (kt + 2) % 3
+            FC_DMA8(kn, sn)
+            const char* sA = smc + st * STAGE8 + a_row;
+            const char* sB = smc + st * STAGE8 + b_row;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f16x8 af8[TM][2], bf8[TN][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int off = ((sub * 4 + q * 2 + lh) ^ xsw) * 16;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af8[i][q] = *reinterpret_cast<const f16x8*>(sA + i * 32 * ROWB8 + off);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf8[j][q] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB8 + off);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][0], bf8[j][0], acc[i][j], 0, 0, 0);     /* hi * hi */
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][0], bf8[j][1], corr[i][j], 0, 0, 0);   /* hi * lo' */
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][1], bf8[j][0], corr[i][j], 0, 0, 0);   /* lo' * hi */
+                    }
+            }
+            st = st == 2 ? 0 : st + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the tail's re-loads: nothing may land in LDS once the epilogue owns it
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += corr[i][j][r] * (1.0f / 2048.0f);
+#undef FC_DMA8
+    } else if constexpr (VAR >= 3) {
         // ================= split-bf16 main loop: fp32-equivalent products on the bf16 matrix cores =================
         // x = hi + mid + lo (three bf16 limbs, 24 significant bits);  a*b ~= ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh),
         // the dropped terms are below 2^-24 |a b|.  Every limb product is exact in the MFMA's fp32 accumulator, so the result
@@ -467,6 +555,7 @@ void gemm_f32_kernel(const GemmParams p) {
         //      [rows, 25*d2] parameter matrix is written to or re-read from HBM.
         static_assert(BN == 128, "spline epilogue: the column layout is built for 128-column tiles");
         constexpr int TP = BN + 1;                                   // odd pitch: lanes walk rows conflict-free
+        if (e.inverse == 2) return;                                  // (diagnostic knob 14: main loop only)
         float* tile = smem;                                          // aliases the staging buffers (all reads are behind the loop's last barrier)
         float* part = smem + BM * TP;                                // [DPT][BM] log-det terms
 #pragma unroll
@@ -485,7 +574,8 @@ void gemm_f32_kernel(const GemmParams p) {
             if (dim0 + dl < e.d2 && m0 + row < e.rows_valid) {
                 float* xp = e.xbuf + (size_t)(m0 + row) * e.ldx + e.x2_col0 + dim0 + dl;
                 float y;
-                rq_any(K, *xp, tile + row * TP + dl * per, 1, false, y, lad);
+                if (e.inverse == 1) { y = *xp + tile[row * TP + dl * per]; lad = tile[row * TP + dl * per + 1]; }   // (diagnostic knob 14: no spline evaluation)
+                else rq_any(K, *xp, tile + row * TP + dl * per, 1, false, y, lad);
                 *xp = y;
             }
             part[dl * BM + row] = lad;
@@ -569,7 +659,7 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_lnq_fold = 1, g_fused_spline = 1;     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_lnq_fold = 1, g_fused_spline = 1, g_gemm_dma = 0, g_spline_ablate = 0;   // g_gemm_dma (knob 13): the LDS-DMA loop (VAR 8) for the fused spline GEMM -- bit-identical results, measured 2.6 % slower than VAR 7     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
@@ -599,7 +689,7 @@ bool Fp16Guard::overflowed() {
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds_main = (VAR == 5 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
     constexpr size_t lds_epi = EPI == EPI_SPLINE ? ((size_t)BM * (BN + 1) + (size_t)BM * 9) * sizeof(float) : 0;   // tile + <= 9 dims of log-dets
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
@@ -683,13 +773,15 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         launch_cfg<128, 128, 4, 2, EPI_LNQ, 5>(p, s);
     } else if (epi_kind == EPI_SPLINE) {
         const int K = e.spline_K;
+        p.e.inverse = g_spline_ablate;
         if (!split) throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: the fused spline epilogue exists for the split GEMM loops only");
         if ((K != 4 && K != 8 && K != 16) || L.N_pad != spline_ncols(e.d2, K) || !e.xbuf || !e.ldj_part || e.ldj_pitch < (size_t)rows_alloc)
             throw Error(FC_ERR_INVALID, "launch_gemm: bad fused-spline arguments (layout of spline.h, per-tile log-det buffer)");
         p.nbm = rows_alloc / 128;
         if (f16 && e.A16 && g_gemm_bigtile == 3) {
             if (L.nseg != 1) throw Error(FC_ERR_INVALID, "launch_gemm: a limb-image A operand must be the only segment");
-            launch_cfg<128, 128, 4, 2, EPI_SPLINE, 7>(p, s);
+            if (g_gemm_dma && rows_alloc % 256 == 0 && L.n_alloc >= round_up(L.N_pad, 128)) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_SPLINE, 8>(p, s); }
+            else launch_cfg<128, 128, 4, 2, EPI_SPLINE, 7>(p, s);
         }
         else if (f16 && g_gemm_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_SPLINE, 5>(p, s);
         else if (f16) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 5>(p, s);

@@ -16,7 +16,7 @@ struct TmpBuf {
 }  // namespace fc
 
 
-namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; }
+namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }
 
 extern "C" {
@@ -33,6 +33,8 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 10) fc::g_lnq_fold = value;
     else if (key == 11) fc::g_train_wgrad16 = value;
     else if (key == 12) fc::g_train_attn16 = value;
+    else if (key == 13) fc::g_gemm_dma = value;
+    else if (key == 14) fc::g_spline_ablate = value;     /* diagnostic: 1 = fused spline epilogue without the spline evaluation, 2 = main loop only (results invalid) */
     else return FC_ERR_INVALID;
     return FC_OK;
 }

@@ -208,7 +208,7 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
     eps = [torch.randn(B, N, 294, generator=g).to(DEV)]
     batch = (e0.to(DEV), e1.to(DEV), None)
-    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 0, 9: 1, 10: 1}
+    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 0, 9: 1, 10: 1, 13: 0}
     try:
         _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
         for name, knobs in (("unfused spline", {7: 0}), ("fused pre-attention chain kernel", {8: 1}), ("separate LayerNorm + q projection", {10: 0}), ("no limb chain", {9: 0}), ("fp32-input attention", {5: 0}),
@@ -221,6 +221,12 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
             err = (lp - ref).abs().max().item()
             print(f"{name}: max |log-prob - default path| {err:.2e}")
             assert err < 5e-4, name
+        # the LDS-DMA main loop of the fused spline GEMM (256x128 tile, global_load_lds ring) issues the same MFMAs in the same order as
+        # the shipped register-staged loop: bit-identical log-probs
+        lib.fc_debug_set(13, 1)
+        _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+        lib.fc_debug_set(13, 0)
+        assert torch.equal(lp, ref), "LDS-DMA spline GEMM differs from the register-staged loop"
     finally:
         for k, v in defaults.items():
             lib.fc_debug_set(k, v)
