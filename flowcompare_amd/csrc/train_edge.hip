@@ -1,5 +1,6 @@
 // Training primitives for the DGCNN context embedder (models/pytorch_gcn.py:23-47, 81-107): one EdgeConv level
-//     y_ij = W cat(f_j - f_i, f_i)  ->  BatchNorm2d with BATCH statistics over (scene, point, neighbour)  ->  LeakyReLU(0.2)  ->  max over the k neighbours
+//     y_ij = W cat(f_j - f_i, f_i)  ->  BatchNorm2d with BATCH statistics over (scene, point, neighbour)  ->  LeakyReLU(slope)  ->  max over the k neighbours
+// (slope 0.2 for the DGCNN; slope 0 = ReLU for the PAConv embedder's BatchNorm + ReLU (+ max over the 32 neighbours), train_paconv.hip)
 // forward and backward.  By linearity y_ij = P[idx_ij] + Q[i] with P = f Wa^T, Q = f (Wb - Wa)^T (W = [Wa | Wb]), so the [points, k, C]
 // edge tensor is never formed by a GEMM: the two per-point products come from the training Linear (train.hip) and these kernels gather.
 // With idx == NULL (k = 1, identity) and Q == NULL the same kernels are BatchNorm1d + LeakyReLU on a [points, C] matrix (conv5).
@@ -65,7 +66,8 @@ __global__ void edge_stats_reduce_kernel(const double* __restrict__ part, int S,
 }
 
 __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeParams e, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float* __restrict__ out, int ldo, unsigned char* __restrict__ arg) {
+                                                       const float* __restrict__ beta, float* __restrict__ out, int ldo, unsigned char* __restrict__ arg,
+                                                       float slope) {
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + q;
     if (i >= e.rows) return;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeParams e, const float
         int bj = 0;
         for (int j = 0; j < e.k; ++j) {
             const float u = a * edge_y(e, i, j, c) + b;
-            const float z = u > 0.f ? u : 0.2f * u;
+            const float z = u > 0.f ? u : slope * u;
             if (z > best) { best = z; bj = j; }
         }
         out[(size_t)i * ldo + c] = best;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeParams e, const float
 __global__ __launch_bounds__(256) void edge_bwd_prep_kernel(EdgeParams e, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const unsigned char* __restrict__ arg,
                                                             const float* __restrict__ g, int ldg, float* __restrict__ t1, float* __restrict__ t2, int ldt,
-                                                            int rows_pad) {
+                                                            int rows_pad, float slope) {
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + q;
     if (i >= rows_pad) return;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void edge_bwd_prep_kernel(EdgeParams e, const 
         if (i < e.rows) {
             const float xh = (edge_y(e, i, arg[(size_t)i * e.C + c], c) - stats[c]) * stats[e.C + c];
             const float u = gamma[c] * xh + beta[c];
-            a1 = g[(size_t)i * ldg + c] * (u > 0.f ? 1.0f : 0.2f);
+            a1 = g[(size_t)i * ldg + c] * (u > 0.f ? 1.0f : slope);
             a2 = a1 * xh;
         }
         t1[(size_t)i * ldt + c] = a1;
@@ -227,27 +229,27 @@ int fc_train_edge_stats_f32(const float* P, int32_t ldp, const float* Q, int32_t
 }
 
 int fc_train_edge_fwd_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
-                          const float* stats, const float* gamma, const float* beta, float* out, int32_t ldo, uint8_t* arg, void* stream) {
+                          const float* stats, const float* gamma, const float* beta, float slope, float* out, int32_t ldo, uint8_t* arg, void* stream) {
     FC_API_BEGIN
     const EdgeParams e = edge_params(P, ldp, Q, ldq, idx, rows, k, C, "fc_train_edge_fwd_f32");
     if (!stats || !gamma || !beta || !out || !arg || ldo < C) throw Error(FC_ERR_INVALID, "fc_train_edge_fwd_f32: bad argument");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("fc::edge_fwd_kernel", 0.0, (double)rows * k * C * 4.0, s);
-    hipLaunchKernelGGL(edge_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, e, stats, gamma, beta, out, ldo, arg);
+    hipLaunchKernelGGL(edge_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, e, stats, gamma, beta, out, ldo, arg, slope);
     FC_HIP(hipGetLastError());
     FC_API_END
 }
 
 /* t1, t2 [rows_pad, ldt]: g lrelu'(u*) and that times xhat*, zeros beyond `rows` (column sums = d beta, d gamma) */
 int fc_train_edge_bwd_prep_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
-                               const float* stats, const float* gamma, const float* beta, const uint8_t* arg, const float* g, int32_t ldg, float* t1,
-                               float* t2, int32_t ldt, int32_t rows_pad, void* stream) {
+                               const float* stats, const float* gamma, const float* beta, float slope, const uint8_t* arg, const float* g, int32_t ldg,
+                               float* t1, float* t2, int32_t ldt, int32_t rows_pad, void* stream) {
     FC_API_BEGIN
     const EdgeParams e = edge_params(P, ldp, Q, ldq, idx, rows, k, C, "fc_train_edge_bwd_prep_f32");
     if (!stats || !gamma || !beta || !arg || !g || !t1 || !t2 || ldg < C || ldt < C || rows_pad < rows) throw Error(FC_ERR_INVALID, "fc_train_edge_bwd_prep_f32: bad argument");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("fc::edge_bwd_prep_kernel", 0.0, (double)rows * C * 16.0, s);
-    hipLaunchKernelGGL(edge_bwd_prep_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, s, e, stats, gamma, beta, arg, g, ldg, t1, t2, ldt, rows_pad);
+    hipLaunchKernelGGL(edge_bwd_prep_kernel, dim3((rows_pad + 3) / 4), dim3(256), 0, s, e, stats, gamma, beta, arg, g, ldg, t1, t2, ldt, rows_pad, slope);
     FC_HIP(hipGetLastError());
     FC_API_END
 }

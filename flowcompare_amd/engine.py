@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FCFLOW_LIB", os.path.join(_HERE, "libfcflow.so"))   # FCFLOW_LIB: A/B another build in profiles/kernel_bench.py
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 FLOW_TYPES = {"AffineCoupling": 0, "RationalQuadraticSplineCoupling": 1, "ExponentialCoupling": 2}
 SCALE_FNS = {"exp": 0, "sigmoid": 1}
@@ -36,6 +36,8 @@ EXPORTS = [
     "fc_train_affine_fwd_f32", "fc_train_affine_bwd_f32", "fc_train_gauss_fwd_f32", "fc_train_gauss_bwd_f32", "fc_train_base_fwd_f32", "fc_train_base_bwd_f32",
     "fc_train_normlp_fwd_f32", "fc_train_normlp_bwd_f32", "fc_train_expm_fwd_f32", "fc_train_expm_bwd_f32",
     "fc_train_edge_ws_bytes", "fc_train_edge_stats_f32", "fc_train_edge_fwd_f32", "fc_train_edge_bwd_prep_f32", "fc_train_edge_bwd_scatter_f32", "fc_train_edge_bwd_gather_f32", "fc_train_pool_fwd_f32", "fc_train_pool_bwd_f32",
+    "fc_op_paconv_knn_f32", "fc_train_paconv_group_f32", "fc_train_softmax_fwd_f32", "fc_train_softmax_bwd_f32", "fc_train_assign_fwd_f32", "fc_train_assign_bwd_f32",
+    "fc_train_centerdiff_fwd_f32", "fc_train_centerdiff_bwd_f32", "fc_train_rows_gather_bwd_f32", "fc_train_three_nn_f32", "fc_train_interp_fwd_f32",
 ]
 
 

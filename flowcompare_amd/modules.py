@@ -457,7 +457,7 @@ class PointNet2FPModule(_Container):
 class PointNet2SSGSeg(nn.Module):
     """PAConv context embedder: 4 set-abstraction levels (FPS to n/4, 32-NN grouping, 3 PAConv layers, max) + 4 feature
     propagation levels (3-NN inverse-distance interpolation, skip concat, shared MLP) + head MLP."""
-    TRAINABLE = False      # no backward kernels for this embedder: initialize_flow(mode='train') keeps it frozen in eval() mode
+    TRAINABLE = True       # train() mode runs the differentiable HIP path (train_paconv.py); False would keep it frozen in eval() mode
 
     def __init__(self, c=3, k=13, use_xyz=True, out_mlp_dims=(512, 512, 512), args=None):
         super().__init__()
@@ -477,5 +477,9 @@ class PointNet2SSGSeg(nn.Module):
         return self._handle
 
     def forward(self, pointcloud):
-        """pointcloud [B,M,3+c] (xyz first) -> [B,M,k]."""
+        """pointcloud [B,M,3+c] (xyz first) -> [B,M,k].  In train() mode: the differentiable HIP path with BatchNorm batch statistics
+        (train_paconv.py); in eval() mode the fused inference engine (running statistics)."""
+        if self.training:
+            from . import train_paconv
+            return train_paconv.paconv_embed(self, pointcloud)
         return self._engine().embed(pointcloud)

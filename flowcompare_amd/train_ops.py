@@ -535,7 +535,7 @@ class EdgeBNMaxFn(torch.autograd.Function):
             engine._check(L.fc_train_edge_stats_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, ctypes.c_float(bn.eps),
                                                     engine._ptr(stats), engine._ptr(ws), ctypes.c_size_t(nb), s))
             engine._check(L.fc_train_edge_fwd_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats), engine._ptr(g32),
-                                                  engine._ptr(b32), engine._ptr(out), C, engine._ptr(arg), s))
+                                                  engine._ptr(b32), ctypes.c_float(0.2), engine._ptr(out), C, engine._ptr(arg), s))
         if bn.track_running_stats and bn.running_mean is not None:
             # torch.nn.BatchNorm train-mode side effect (parameter-sized vectors): running <- (1 - m) running + m batch, unbiased variance
             with torch.no_grad():
@@ -571,8 +571,8 @@ class EdgeBNMaxFn(torch.autograd.Function):
         with _OnDevice(dev):
             s = engine._stream()
             engine._check(L.fc_train_edge_bwd_prep_f32(engine._ptr(pq), ld, q_ptr, ld, engine._ptr(idx), rows, k, C, engine._ptr(stats), engine._ptr(g32),
-                                                       engine._ptr(b32), engine._ptr(arg), engine._ptr(g), g.shape[1], engine._ptr(t1), engine._ptr(t2),
-                                                       C, rows_pad, s))
+                                                       engine._ptr(b32), ctypes.c_float(0.2), engine._ptr(arg), engine._ptr(g), g.shape[1], engine._ptr(t1),
+                                                       engine._ptr(t2), C, rows_pad, s))
             dbeta, dgamma = _colsum(t1, C, rows), _colsum(t2, C, rows)
             dq_ptr = ctypes.c_void_p(dpq.data_ptr() + 4 * C) if has_q else ctypes.c_void_p(0)
             if has_q:

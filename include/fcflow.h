@@ -16,7 +16,9 @@
  *     pointer); folding / padding / packing for the kernels happens inside create.
  * ABI history: 1 = forward log-prob engine; 2 = + inverse / sampling, staging and change-map entries, profiler filter;
  * 3 = + the stateless training primitives fc_train_* (forward AND backward of every node of the path, no handles: parameters stay
- *     the caller's dense fp32 device tensors because they change every optimiser step).
+ *     the caller's dense fp32 device tensors because they change every optimiser step);
+ * 4 = + the PAConv embedder's training primitives (softmax / assign_score / centre difference / gathered-row gradients / 3-NN
+ *     interpolation), LeakyReLU slope argument of fc_train_edge_fwd_f32 / fc_train_edge_bwd_prep_f32 (0 = ReLU).
  */
 #ifndef FCFLOW_H
 #define FCFLOW_H
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 3
+#define FC_ABI_VERSION 4
 
 enum fc_status {
     FC_OK = 0,
@@ -285,7 +287,7 @@ int fc_train_colsum_f32(const float* a, int32_t lda, int32_t cols, int32_t rows,
 
 /* One EdgeConv level of the DGCNN embedder in TRAINING mode (models/pytorch_gcn.py:23-47, 81-99): y_ij = P[idx_ij] + Q[i] (the 1x1
  * conv of cat(f_j - f_i, f_i) split by linearity into two per-point products), BatchNorm with batch statistics over all (i, j),
- * LeakyReLU(0.2), max over the k neighbours -- forward and backward.  idx [rows, k] holds GLOBAL row indices (k <= 255); idx == NULL
+ * LeakyReLU(slope) (0.2 in the DGCNN, 0 = the PAConv embedder's ReLU), max over the k neighbours -- forward and backward.  idx [rows, k] holds GLOBAL row indices (k <= 255); idx == NULL
  * with k == 1 and Q == NULL is BatchNorm1d + LeakyReLU on a [rows, C] matrix (conv5).  stats [3C] = mean | rstd | biased variance.
  * bwd: prep -> column sums of t1, t2 (fc_train_colsum_f32) = d beta, d gamma -> scatter (dQ; dP by float atomics into a zeroed buffer, or
  * dP = NULL and fc_train_edge_bwd_gather_f32 over the edges sorted by target: fixed summation order, bit-reproducible). */
@@ -293,10 +295,10 @@ size_t fc_train_edge_ws_bytes(int32_t rows, int32_t C);
 int fc_train_edge_stats_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C, float eps,
                             float* stats, void* ws, size_t ws_bytes, void* stream);
 int fc_train_edge_fwd_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
-                          const float* stats, const float* gamma, const float* beta, float* out, int32_t ldo, uint8_t* arg, void* stream);
+                          const float* stats, const float* gamma, const float* beta, float slope, float* out, int32_t ldo, uint8_t* arg, void* stream);
 int fc_train_edge_bwd_prep_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
-                               const float* stats, const float* gamma, const float* beta, const uint8_t* arg, const float* g, int32_t ldg, float* t1,
-                               float* t2, int32_t ldt, int32_t rows_pad, void* stream);
+                               const float* stats, const float* gamma, const float* beta, float slope, const uint8_t* arg, const float* g, int32_t ldg,
+                               float* t1, float* t2, int32_t ldt, int32_t rows_pad, void* stream);
 /* Pooling of the global embedder (models/pytorch_gcn.py:178-182): out [B, >= 2 width] = [max over the scene's M points | mean],
  * arg [B, width] = arg-max point; bwd: dt [B*M, lddt]. */
 int fc_train_pool_fwd_f32(const float* t, int32_t ldt, int32_t width, int32_t B, int32_t M, float* out, int32_t ldo, int32_t* arg, void* stream);
@@ -307,6 +309,28 @@ int fc_train_edge_bwd_gather_f32(const float* P, int32_t ldp, const float* Q, in
 int fc_train_edge_bwd_scatter_f32(const float* P, int32_t ldp, const float* Q, int32_t ldq, const int32_t* idx, int32_t rows, int32_t k, int32_t C,
                                   const float* stats, const float* gamma, const uint8_t* arg, const float* t1, int32_t ldt, const float* dbeta,
                                   const float* dgamma, float* dP, int32_t lddp, float* dQ, int32_t lddq, void* stream);
+
+/* ---- PAConv context embedder, training primitives (models/scene_seg_PAConv/model/pointnet2/paconv.py:31-54, 107-153; util/paconv_util.py:52-56;
+ * lib/pointops/src/grouping/grouping_cuda_kernel.cu:28-46; lib/pointops/src/interpolation/interpolation_cuda_kernel.cu:90-195).  Row-major fp32
+ * matrices with explicit pitches; *_pad arguments: rows the OUTPUT buffers hold (pad rows / columns are zeroed).  Gather backwards take the edges
+ * sorted by source row (order, offsets) and sum in that fixed order -- no atomics. */
+int fc_op_paconv_knn_f32(const float* xyz, const float* qxyz, int32_t* out, int32_t B, int32_t n, int32_t m, int32_t k, void* stream);
+int fc_train_paconv_group_f32(const float* xyz, const float* feat, int32_t ldf, int32_t C, const float* qxyz, const int32_t* nidx, float* E, int32_t ldE,
+                              float* gdiff, int32_t B, int32_t n, int32_t m, int32_t K, void* stream);
+int fc_train_softmax_fwd_f32(const float* x, int32_t ldx, int32_t width, int32_t rows, float* y, int32_t ldy, void* stream);
+int fc_train_softmax_bwd_f32(const float* y, int32_t ldy, const float* dy, int32_t lddy, int32_t width, int32_t rows, int32_t rows_pad, float* dx,
+                             int32_t lddx, void* stream);
+int fc_train_assign_fwd_f32(const float* G, int32_t ldg, const float* S, int32_t lds, int32_t m, int32_t Cout, int32_t rows, int32_t rows_pad, float* out,
+                            int32_t ldo, void* stream);
+int fc_train_assign_bwd_f32(const float* G, int32_t ldg, const float* S, int32_t lds, const float* dout, int32_t lddo, int32_t m, int32_t Cout, int32_t rows,
+                            int32_t rows_pad, float* dG, int32_t lddg, float* dS, int32_t ldds, void* stream);
+int fc_train_centerdiff_fwd_f32(const float* x, int32_t ldx, int32_t C, int32_t K, int32_t groups, float* E, int32_t ldE, void* stream);
+int fc_train_centerdiff_bwd_f32(const float* dE, int32_t ldE, int32_t C, int32_t K, int32_t groups, float* dx, int32_t lddx, void* stream);
+int fc_train_rows_gather_bwd_f32(const float* dout, int32_t ldo, int32_t col0, int32_t C, const int32_t* order, const int32_t* offsets, const float* wts,
+                                 int32_t div, int32_t n_src, int32_t n_src_pad, float* dsrc, int32_t lds, void* stream);
+int fc_train_three_nn_f32(const float* uxyz, const float* kxyz, int32_t B, int32_t nu, int32_t mk, int32_t* idx, float* w, void* stream);
+int fc_train_interp_fwd_f32(const float* Fk, int32_t ldfk, int32_t C, const int32_t* idx, const float* w, int32_t rows, int32_t rows_pad, float* out,
+                            int32_t ldo, void* stream);
 
 #ifdef __cplusplus
 }

@@ -393,7 +393,7 @@ def test_actnorm_data_dependent_init_matches_reference(case):
     md["flow"].eval()
 
 
-@pytest.mark.parametrize("case", ["tiny_affine", "tiny_spline_relu", "spline_L2", "tiny_global_extra"])
+@pytest.mark.parametrize("case", ["tiny_affine", "tiny_spline_relu", "spline_L2", "tiny_global_extra", "paconv_L2"])
 def test_full_training_step_matches_reference_train_mode_gradients(case):
     """The WHOLE path in train() mode -- DGCNN embedder with BatchNorm batch statistics, flow, loss.backward() -- against the gradients
     the reference produced in train mode for the same weights, inputs and noise (tests/golden/grad_*.npz, record "train"): every
@@ -406,7 +406,8 @@ def test_full_training_step_matches_reference_train_mode_gradients(case):
     md["input_embedder"].train()
     Din = cfg["input_dim"]
     e0, e1, ex = fx.t("extract_0").to(DEV), fx.t("extract_1").to(DEV), fx.t("extra")
-    bn1_mean_before = md["input_embedder"].bn1.running_mean.clone()
+    bn1 = next(m for m in md["input_embedder"].modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm))     # DGCNN: bn1; PAConv: the first ScoreNet's
+    bn1_mean_before = bn1.running_mean.clone()
     x = e1[:, :, :Din].clone().requires_grad_(True)
     for m in (md["flow"], md["input_embedder"]):
         m.zero_grad()
@@ -433,7 +434,7 @@ def test_full_training_step_matches_reference_train_mode_gradients(case):
         err = np.abs(got - want).max() / max(want[1], 1e-4 * gnorm)          # (floor: tensors whose exact gradient is zero hold rounding noise only)
         if err > worst:
             worst, worst_name = err, key
-    moved = (md["input_embedder"].bn1.running_mean - bn1_mean_before).abs().max().item()
+    moved = (bn1.running_mean - bn1_mean_before).abs().max().item()
     print(f"{case} (train mode): loss {loss.item():.6f} (ref {float(z['train/loss']):.6f}); d extract_1 rel err {dx_err:.1e}; {len(names)} parameter "
           f"gradients (embedder + flow), worst error / L1 norm {worst:.1e} ({worst_name}); bn1 running mean moved by {moved:.2e}")
     assert dx_err < 5e-4 and worst < 1e-3 and moved > 0
