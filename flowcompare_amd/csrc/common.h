@@ -7,6 +7,7 @@
 #include <vector>
 #include <map>
 #include <stdexcept>
+#include <mutex>
 
 #include "../../include/fcflow.h"
 
@@ -55,13 +56,22 @@ struct ProfScope {
 };
 
 // ---------------------------------------------------------------- device memory owned by a handle
+// Thread-safe (the flow's layers are packed by several host threads): 64 MiB chunks, 256-byte aligned sub-allocations, one hipMalloc
+// per chunk instead of one per tensor (a 115-layer flow packs ~4000 tensors).
 struct DeviceArena {
     std::vector<void*> blocks;
     size_t total = 0;
-    float* alloc_floats(size_t n);
+    void* alloc_bytes(size_t n);
+    float* alloc_floats(size_t n) { return (float*)alloc_bytes((n ? n : 1) * sizeof(float)); }
     float* upload(const std::vector<float>& host);
     ~DeviceArena();
+private:
+    std::mutex mu;
+    char* cur = nullptr;
+    size_t cur_left = 0;
 };
+// fp16 / bf16 limb images of a packed fp32 weight matrix already on the device (misc.hip): [rows][K_pad/16][2 or 3][16]
+void launch_limb_images(const float* W, int rows, int K_pad, unsigned short* W3, unsigned short* W2, hipStream_t s);
 
 // ---------------------------------------------------------------- workspace carving (caller-owned memory)
 struct WsCarver {

@@ -15,6 +15,11 @@
 #include <memory>
 #include <cstring>
 
+#include <atomic>
+#include <exception>
+#include <mutex>
+#include <thread>
+
 #include "hostpack.h"
 #include "spline.h"
 
@@ -42,6 +47,7 @@ struct CifPack {
     float* post_scale = nullptr;  // g[k] = exp(-log_scale) of the x part (behind s)
     float* z2_shift = nullptr;    // ActNorm of the z2 part: v = (z2 - shift) * scale
     float* z2_scale = nullptr;
+    double log_const = 0.0;       // data-independent log-det of the CIF ActNorm
 };
 
 struct BlockPack {
@@ -58,6 +64,7 @@ struct BlockPack {
     VecD lin_b;
     bool has_lin_inv = false;
     PackedLinear lin_inv;
+    double log_const = 0.0;       // data-independent log-dets of this block's ActNorm + permuter
 };
 
 struct Dims {
@@ -95,7 +102,7 @@ static int pad_inner(int I) {
 }
 
 // q' = c * Wq (gamma . n + beta),  c = inner^-0.5 * log2(e)   (models/perceiver.py:18-26, 96-110)
-static void build_attn(fc_flow& f, const WeightTable& wt, const std::string& p, AttnPack& out, std::vector<MatD>& kv_rows) {
+static void build_attn(fc_flow& f, const WeightTable& wt, const std::string& p, AttnPack& out, std::vector<MatD>& kv_rows, int slot) {
     Dims& d = f.d;
     const HostTensor& wq_t = wt.get(p + ".fn.attention.to_q.weight");
     if (wq_t.shape.size() != 2) throw Error(FC_ERR_SHAPE, p + ".fn.attention.to_q.weight must be 2-D");
@@ -119,8 +126,8 @@ static void build_attn(fc_flow& f, const WeightTable& wt, const std::string& p, 
     MatD blk(2 * d.I_pad, d.E);
     for (int i = 0; i < I; ++i)
         for (int k = 0; k < d.E; ++k) { blk.at(i, k) = wkv.at(i, k); blk.at(d.I_pad + i, k) = wkv.at(I + i, k); }
-    out.kv_col = (int)kv_rows.size() * 2 * d.I_pad;
-    kv_rows.push_back(blk);
+    out.kv_col = slot * 2 * d.I_pad;            // column block of this attention in the stacked K|V projection
+    kv_rows[slot] = blk;
     const HostTensor& wl = wt.get(p + ".fn.lin.weight");
     if (wl.shape.size() != 2 || wl.shape[1] != I) throw Error(FC_ERR_SHAPE, p + ".fn.lin.weight: expected [attn_dim, inner]");
     out.lin_w = mat_from(wl);
@@ -222,7 +229,7 @@ static void build_lin(fc_flow& f, const WeightTable& wt, int idx_actnorm, int id
         const std::string p = "transforms." + std::to_string(idx_actnorm);
         shift = vec_from(wt.get(p + ".shift", {1, D}));
         ls = vec_from(wt.get(p + ".log_scale", {1, D}));
-        for (double v : ls) f.log_const -= v;
+        for (double v : ls) blk.log_const -= v;
     }
     const std::string p = "transforms." + std::to_string(idx_perm);
     MatD Wp(D, D);
@@ -240,7 +247,7 @@ static void build_lin(fc_flow& f, const WeightTable& wt, int idx_actnorm, int id
             for (int i = 0; i < D; ++i) {
                 const double dg = softplus_d(ud.data[i]) + (double)f.cfg.linear_lu_eps;
                 U.at(i, i) = dg;
-                f.log_const += std::log(dg);
+                blk.log_const += std::log(dg);
             }
             Wp = matmul(L, U);               // z = L (U x)   (permuters.py:164-169)
             break;
@@ -256,7 +263,7 @@ static void build_lin(fc_flow& f, const WeightTable& wt, int idx_actnorm, int id
         }
         case FC_PERM_FULL: {
             Wp = mat_from(wt.get(p + ".w", {D, D}));
-            f.log_const += slogdet_abs(Wp);
+            blk.log_const += slogdet_abs(Wp);
             break;
         }
         case FC_PERM_EXPONENTIAL: {
@@ -264,7 +271,7 @@ static void build_lin(fc_flow& f, const WeightTable& wt, int idx_actnorm, int id
             const double sc = wt.get(p + ".scale", {1}).data[0], sh = wt.get(p + ".shift", {1}).data[0];
             const double rs = wt.get(p + ".rescale", {1}).data[0], rsh = wt.get(p + ".reshift", {1}).data[0];
             for (auto& e : w.v) e = rs * std::tanh(sc * e + sh) + rsh + 1e-8;
-            for (int i = 0; i < D; ++i) f.log_const += w.at(i, i);
+            for (int i = 0; i < D; ++i) blk.log_const += w.at(i, i);
             Wp = expm_double(w);
             break;
         }
@@ -350,7 +357,7 @@ static void build_cif(fc_flow& f, const WeightTable& wt, const std::string& p, C
                                        map_prefix(hl, round_up(hl, 32)), {round_up(hl, 32)});
     }
     VecD shift = vec_from(wt.get(p + ".act_norm.shift", {1, Dc})), ls = vec_from(wt.get(p + ".act_norm.log_scale", {1, Dc}));
-    for (double v : ls) f.log_const -= v;
+    for (double v : ls) c.log_const -= v;
     std::vector<float> g(gemm_n_alloc(round_up(D, 32) * 2), 0.f), sh2(gemm_n_alloc(round_up(nz, 32) * 2), 0.f), g2(sh2.size(), 1.f);
     for (int k = 0; k < D; ++k) g[k] = (float)std::exp(-ls[Dc - 1 - k]);
     for (int j = 0; j < nz; ++j) { sh2[j] = (float)shift[nz - 1 - j]; g2[j] = (float)std::exp(-ls[nz - 1 - j]); }
@@ -379,7 +386,6 @@ static void build_cif(fc_flow& f, const WeightTable& wt, const std::string& p, C
         }
         c.aff.out_layer = pack_linear(f.arena, wo, bo, {}, map_pairs_rows(srow, trow), map_prefix(hl, round_up(hl, 32)), {round_up(hl, 32)});
     }
-    d.H_pad = std::max({d.H_pad, max_hidden_pad(c.dist), max_hidden_pad(c.aff)});
 }
 
 static void build_flow(fc_flow& f, const WeightTable& wt) {
@@ -398,14 +404,15 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
     d.E = c.input_embedding_dim; d.E_pad = round_up(d.E, 32); d.X = c.extra_context_dim;
     if (d.Din > 32) throw Error(FC_ERR_UNSUPPORTED, "input_dim > 32");
     d.Dc = c.cif_latent_dim; d.nz = d.Dc - d.D; d.nz_pad = round_up(std::max(d.nz, 1), 32);
-    std::vector<MatD> kv_rows;
+    f.has_augment = d.D > d.Din;
+    const int aug_slots = f.has_augment ? 1 : 0;
+    std::vector<MatD> kv_rows(aug_slots + (c.global_context ? 0 : c.n_flow_layers));
+    std::mutex dims_mu;                          // d.H_pad / d.ldp maxima are the only shared writes of the per-layer builders
 
     // ---- transform 0: AugmentAttentionPreconditioner (models/augmenter.py:7-22) or IdentityTransform
-    int idx = 1;
-    f.has_augment = d.D > d.Din;
     if (f.has_augment) {
         const std::string p = "transforms.0";
-        build_attn(f, wt, p + ".attn", f.aug_attn, kv_rows);
+        build_attn(f, wt, p + ".attn", f.aug_attn, kv_rows, 0);
         pack_mlp_mid(f.arena, wt, p + ".pre_attn_mlp", f.aug_pre);
         f.aug_pre.in_layer = build_plain(f, wt, p + ".pre_attn_mlp.in_layer", d.Din, 32);
         f.aug_pre.out_layer = build_plain(f, wt, p + ".pre_attn_mlp.out_layer", f.aug_pre.sizes.back(), round_up(f.aug_pre.sizes.back(), 32));
@@ -420,45 +427,75 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
                                           map_prefix(hl, round_up(hl, 32)), {round_up(hl, 32)});
         d.H_pad = std::max({d.H_pad, max_hidden_pad(f.aug_pre), max_hidden_pad(f.aug_net), d.A_in_pad});
     }
-    // ---- blocks
+    // ---- blocks.  Layer l's transforms are [block, ActNorm?, permuter] at indices 1 + l * stride ...; the layers are independent, so
+    //      after layer 0 (which fixes the shared attention dims) they are packed by a pool of host threads: the double-precision folds
+    //      and the fp32 packing of 370 M weights (C2) are the bulk of fc_flow_create's time.
     f.blocks.resize(c.n_flow_layers);
-    for (int l = 0; l < c.n_flow_layers; ++l) {
+    const int stride = 2 + (c.act_norm ? 1 : 0);
+    auto build_block = [&](int l) {
         BlockPack& b = f.blocks[l];
-        std::string p = "transforms." + std::to_string(idx++);
+        const int idx0 = 1 + l * stride;
+        std::string p = "transforms." + std::to_string(idx0);
         b.has_attn = !c.global_context;
         b.has_cif = cif;
+        int h_pad = 0, ldp = 0;
         if (cif) {
             build_cif(f, wt, p, b.cif);
+            h_pad = std::max({h_pad, max_hidden_pad(b.cif.dist), max_hidden_pad(b.cif.aff)});
             p += ".flow";                              // the conditioned coupling lives one level down (cif_block.py:65)
         }
         if (b.has_attn) {
-            build_attn(f, wt, p + ".pre_conditioner.attn", b.attn, kv_rows);
+            build_attn(f, wt, p + ".pre_conditioner.attn", b.attn, kv_rows, aug_slots + l);
             const std::string pp = p + ".pre_conditioner.pre_attention_mlp";
             pack_mlp_mid(f.arena, wt, pp, b.pre);
             b.pre.in_layer = build_plain(f, wt, pp + ".in_layer", d.d1, d.d1_pad);
             b.pre.out_layer = build_plain(f, wt, pp + ".out_layer", b.pre.sizes.back(), round_up(b.pre.sizes.back(), 32));
             if (b.pre.out_layer.N_pad != d.A_in_pad) throw Error(FC_ERR_SHAPE, "pre_attention_mlp output width != attn_input_dim");
             build_lnq(f, wt, pp + ".out_layer", b.attn);
-            d.H_pad = std::max({d.H_pad, max_hidden_pad(b.pre), d.A_in_pad});
+            h_pad = std::max({h_pad, max_hidden_pad(b.pre), d.A_in_pad});
         }
         const std::string pn = p + ".transform.nn";
         pack_mlp_mid(f.arena, wt, pn, b.net);
         b.net.in_layer = build_in_layer(f, wt, pn, d.d1, d.d1_pad, b.has_attn ? &b.attn : nullptr);
         build_out_layer(f, wt, pn, b.net);
-        d.H_pad = std::max(d.H_pad, max_hidden_pad(b.net));
-        if (c.flow_type != FC_FLOW_AFFINE) d.ldp = std::max(d.ldp, b.net.out_layer.N_pad);
+        h_pad = std::max(h_pad, max_hidden_pad(b.net));
+        if (c.flow_type != FC_FLOW_AFFINE) ldp = b.net.out_layer.N_pad;
         if (c.flow_type == FC_FLOW_EXPONENTIAL) {
             const std::string pt = p + ".transform";
             std::vector<float> sc = {wt.get(pt + ".scale", {1}).data[0], wt.get(pt + ".shift", {1}).data[0],
                                      wt.get(pt + ".rescale", {1}).data[0], wt.get(pt + ".reshift", {1}).data[0]};
             b.expm_scal = f.arena.upload(sc);
         }
-        if (l != c.n_flow_layers - 1) {
-            const int ia = c.act_norm ? idx++ : -1;
-            const int ip = idx++;
-            build_lin(f, wt, ia, ip, b);
-        }
+        if (l != c.n_flow_layers - 1) build_lin(f, wt, c.act_norm ? idx0 + 1 : -1, idx0 + stride - 1, b);
+        std::lock_guard<std::mutex> lock(dims_mu);
+        d.H_pad = std::max(d.H_pad, h_pad);
+        d.ldp = std::max(d.ldp, ldp);
+    };
+    build_block(0);
+    {
+        int dev = 0;
+        FC_HIP(hipGetDevice(&dev));
+        const int n_workers = std::max(1, std::min({(int)std::thread::hardware_concurrency(), 16, c.n_flow_layers - 1}));
+        std::atomic<int> next{1};
+        std::exception_ptr first_error;
+        std::mutex err_mu;
+        auto worker = [&]() {
+            try {
+                if (hipSetDevice(dev) != hipSuccess) throw Error(FC_ERR_HIP, "hipSetDevice failed in a packing thread");
+                for (int l = next.fetch_add(1); l < c.n_flow_layers; l = next.fetch_add(1)) build_block(l);
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(err_mu);
+                if (!first_error) first_error = std::current_exception();
+                next.store(c.n_flow_layers);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_workers; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+        if (first_error) std::rethrow_exception(first_error);
     }
+    for (const BlockPack& b : f.blocks) f.log_const += b.cif.log_const + b.log_const;      // fixed order: reproducible
     // ---- one stacked K|V projection for every attention
     f.n_attn = (int)kv_rows.size();
     if (f.n_attn) {

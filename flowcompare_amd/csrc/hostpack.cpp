@@ -76,12 +76,28 @@ std::string prof_report_json() {
 }
 
 // ---------------------------------------------------------------- arena
-float* DeviceArena::alloc_floats(size_t n) {
-    void* p = nullptr;
-    FC_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)));
-    blocks.push_back(p);
-    total += n * sizeof(float);
-    return (float*)p;
+void* DeviceArena::alloc_bytes(size_t n) {
+    constexpr size_t CHUNK = 64u << 20;
+    n = round_up_sz(std::max<size_t>(n, 1), 256);
+    std::lock_guard<std::mutex> lock(mu);
+    total += n;
+    if (n > CHUNK / 4) {                                  // large tensors get their own allocation
+        void* p = nullptr;
+        FC_HIP(hipMalloc(&p, n));
+        blocks.push_back(p);
+        return p;
+    }
+    if (n > cur_left) {
+        void* p = nullptr;
+        FC_HIP(hipMalloc(&p, CHUNK));
+        blocks.push_back(p);
+        cur = (char*)p;
+        cur_left = CHUNK;
+    }
+    void* out = cur;
+    cur += n;
+    cur_left -= n;
+    return out;
 }
 float* DeviceArena::upload(const std::vector<float>& host) {
     float* d = alloc_floats(host.size());
@@ -332,22 +348,15 @@ PackedLinear pack_linear(DeviceArena& arena, const MatD& W, const VecD& bias, co
     L.W = arena.upload(w);
     L.bias = arena.upload(b);
     if (g_pack_bf16_limbs && L.K_pad % 16 == 0) {
-        const std::vector<unsigned short> w3 = make_bf16_limbs(w, L.n_alloc, L.K_pad);
-        void* d = nullptr;
-        FC_HIP(hipMalloc(&d, w3.size() * sizeof(unsigned short)));
-        arena.blocks.push_back(d);
-        arena.total += w3.size() * sizeof(unsigned short);
-        FC_HIP(hipMemcpy(d, w3.data(), w3.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-        L.W3 = (unsigned short*)d;
-        const std::vector<unsigned short> w2 = make_f16_limbs(w, L.n_alloc, L.K_pad);
-        if (!w2.empty()) {
-            void* d2 = nullptr;
-            FC_HIP(hipMalloc(&d2, w2.size() * sizeof(unsigned short)));
-            arena.blocks.push_back(d2);
-            arena.total += w2.size() * sizeof(unsigned short);
-            FC_HIP(hipMemcpy(d2, w2.data(), w2.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-            L.W2 = (unsigned short*)d2;
-        }
+        // the limb images are made ON THE DEVICE from the fp32 matrix just uploaded (same roundings as make_*_limbs above, which remain
+        // as the host statement of the layout): the host neither converts nor uploads 10 of the 14 bytes per weight.  A matrix with an
+        // entry outside fp16's range gets no fp16 image (the split-fp16 loop then never runs on it).
+        bool fits16 = true;
+        for (float x : w) if (!(std::fabs(x) < 65504.0f)) { fits16 = false; break; }
+        const size_t n16 = (size_t)L.n_alloc * (L.K_pad / 16);
+        L.W3 = (unsigned short*)arena.alloc_bytes(n16 * 48 * sizeof(unsigned short));
+        L.W2 = fits16 ? (unsigned short*)arena.alloc_bytes(n16 * 32 * sizeof(unsigned short)) : nullptr;
+        launch_limb_images(L.W, L.n_alloc, L.K_pad, L.W3, L.W2, nullptr);
     }
     L.colvec = colvec.empty() ? nullptr : arena.upload(cv);
     return L;

@@ -17,6 +17,38 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---------------------------------------------------------------- limb images of a packed weight matrix (fc_*_create)
+// One thread per (row, k16 block, element): W3 [rows][K/16][3][16] bf16 limbs (hi, mid, lo: x = hi + mid + lo to 24 bits), W2
+// [rows][K/16][2][16] fp16 limbs (hi, lo' = (x - hi) * 2048) -- the roundings of hostpack.cpp make_bf16_limbs / make_f16_limbs.
+__global__ void limb_images_kernel(const float* __restrict__ W, size_t n, int K_pad, unsigned short* __restrict__ W3, unsigned short* __restrict__ W2) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const size_t row = t / K_pad;
+    const int k = (int)(t - row * K_pad);
+    const float x = W[t];
+    const size_t blk = row * (K_pad / 16) + k / 16;
+    const int e = k & 15;
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    W3[blk * 48 + e] = __builtin_bit_cast(unsigned short, h);
+    W3[blk * 48 + 16 + e] = __builtin_bit_cast(unsigned short, m);
+    W3[blk * 48 + 32 + e] = __builtin_bit_cast(unsigned short, l);
+    if (W2) {
+        const _Float16 h16 = (_Float16)x;
+        const _Float16 l16 = (_Float16)((x - (float)h16) * 2048.0f);
+        W2[blk * 32 + e] = __builtin_bit_cast(unsigned short, h16);
+        W2[blk * 32 + 16 + e] = __builtin_bit_cast(unsigned short, l16);
+    }
+}
+void launch_limb_images(const float* W, int rows, int K_pad, unsigned short* W3, unsigned short* W2, hipStream_t s) {
+    const size_t n = (size_t)rows * K_pad;
+    if (!n) return;
+    hipLaunchKernelGGL(limb_images_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, n, K_pad, W3, W2);
+    FC_HIP(hipGetLastError());
+}
+
 // ---------------------------------------------------------------- pack / fill
 // dst[row, dst_col0 + c] = src[row, c] for c < src_cols ; zero for src_cols <= c < zero_to
 __global__ void pack_rows_kernel(const float* __restrict__ src, int src_ld, int src_cols, float* __restrict__ dst, int dst_ld,

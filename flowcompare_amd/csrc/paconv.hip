@@ -23,29 +23,34 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 // One workgroup (1024 threads) per scene; xyz and the running min-distance live in LDS.  The arg-max reproduces the CUDA
 // kernel's tie rule: virtual thread t (t < T = opt_n_threads(n)) scans k = t, t+T, ... keeping its FIRST maximum, and among
 // threads the LOWER thread id wins ties.
-__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz, int ld, int32_t* __restrict__ idx, int n, int m, int T) {
+// BIG (more than 8192 points per scene: the LDS image would not fit): coordinates are read from the input rows and the running
+// min-distance lives in a caller-provided global scratch [B][n]; both stay L2-resident over the m sweeps (same arithmetic, same ties).
+template <bool BIG>
+__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz, int ld, int32_t* __restrict__ idx, int n, int m, int T,
+                                                   float* __restrict__ scratch) {
     extern __shared__ float sm[];
-    float* sx = sm;                 // [n][3]
-    float* st = sm + 3 * n;         // [n]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = xyz + (size_t)b * n * ld;
+    const float* sx = BIG ? src : sm;                       // [n][3] (pitch 3 in LDS, ld in global)
+    const int pitch = BIG ? ld : 3;
+    float* st = BIG ? scratch + (size_t)b * n : sm + 3 * n; // [n]
     __shared__ float red_v[16];
     __shared__ int red_i[16];
     __shared__ int s_old;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* src = xyz + (size_t)b * n * ld;
     for (int k = tid; k < n; k += 1024) {
-        sx[3 * k] = src[(size_t)k * ld]; sx[3 * k + 1] = src[(size_t)k * ld + 1]; sx[3 * k + 2] = src[(size_t)k * ld + 2];
+        if (!BIG) { sm[3 * k] = src[(size_t)k * ld]; sm[3 * k + 1] = src[(size_t)k * ld + 1]; sm[3 * k + 2] = src[(size_t)k * ld + 2]; }
         st[k] = 1e10f;
     }
     if (tid == 0) { idx[(size_t)b * m] = 0; s_old = 0; }
     __syncthreads();
     for (int j = 1; j < m; ++j) {
         const int old = s_old;
-        const float x1 = sx[3 * old], y1 = sx[3 * old + 1], z1 = sx[3 * old + 2];
+        const float x1 = sx[(size_t)pitch * old], y1 = sx[(size_t)pitch * old + 1], z1 = sx[(size_t)pitch * old + 2];
         float best = -1.f;
         int besti = 0;
         if (tid < T)
             for (int k = tid; k < n; k += T) {
-                const float d = sqdist3(sx[3 * k], sx[3 * k + 1], sx[3 * k + 2], x1, y1, z1);
+                const float d = sqdist3(sx[(size_t)pitch * k], sx[(size_t)pitch * k + 1], sx[(size_t)pitch * k + 2], x1, y1, z1);
                 const float d2 = fminf(d, st[k]);
                 st[k] = d2;
                 if (d2 > best) { best = d2; besti = k; }
@@ -82,18 +87,23 @@ static int opt_n_threads_host(int n) {
     int t = 1 << p;
     return t > 1024 ? 1024 : (t < 1 ? 1 : t);
 }
-void launch_fps(const float* xyz, int ld, int32_t* idx, int B, int n, int m, hipStream_t s) {
+size_t fps_scratch_floats(int B, int n) { return n > 8192 ? (size_t)B * n : 0; }
+void launch_fps(const float* xyz, int ld, int32_t* idx, int B, int n, int m, float* scratch, hipStream_t s) {
     if (m <= 0) return;
-    if (n > 8192) throw Error(FC_ERR_UNSUPPORTED, "furthest point sampling: more than 8192 points per scene not supported yet (LDS-resident kernel)");
     if (m > n) throw Error(FC_ERR_INVALID, "furthest point sampling: m > n");
-    const size_t lds = (size_t)n * 4 * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
-        attr_done = true;
-    }
     ProfScope ps("fc::fps_kernel", 0.0, 4.0 * B * (3.0 * n + m), s);
-    hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(1024), lds, s, xyz, ld, idx, n, m, opt_n_threads_host(n));
+    if (n > 8192) {
+        if (!scratch) throw Error(FC_ERR_WORKSPACE, "furthest point sampling: more than 8192 points per scene need the [B][n] min-distance scratch (fps_scratch_floats)");
+        hipLaunchKernelGGL(fps_kernel<true>, dim3(B), dim3(1024), 0, s, xyz, ld, idx, n, m, opt_n_threads_host(n), scratch);
+    } else {
+        const size_t lds = (size_t)n * 4 * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(fps_kernel<false>, dim3(B), dim3(1024), lds, s, xyz, ld, idx, n, m, opt_n_threads_host(n), (float*)nullptr);
+    }
     FC_HIP(hipGetLastError());
 }
 

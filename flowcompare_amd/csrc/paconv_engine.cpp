@@ -12,7 +12,8 @@
 #include "hostpack.h"
 
 namespace fc {
-void launch_fps(const float* xyz, int ld, int32_t* idx, int B, int n, int m, hipStream_t s);
+size_t fps_scratch_floats(int B, int n);
+void launch_fps(const float* xyz, int ld, int32_t* idx, int B, int n, int m, float* scratch, hipStream_t s);
 void launch_gather_xyz(const float* src, int ld, const int32_t* idx, float* dst, int B, int n, int m, hipStream_t s);
 void launch_knn_xyz(const float* xyz, int ld, const float* qxyz, int32_t* out, int B, int n, int m, int k, hipStream_t s);
 void launch_paconv_group(const float* xyz, int ldxyz, const float* feat, int ldf, int C, const float* qxyz, const int32_t* nidx, float* E, int ldE,
@@ -149,7 +150,7 @@ struct PaWs {
     float* feat[5];           // level features, channels-last, pitch ldf[l]
     int ldf[5];
     int32_t *fidx, *nidx;
-    float *gdiff, *scores, *Ea, *Eb, *G, *X, *Ya, *Yb, *h[3], *otmp;
+    float *gdiff, *scores, *Ea, *Eb, *G, *X, *Ya, *Yb, *h[3], *otmp, *fps_tmp;
     int P_pad;
 };
 static PaWs plan_pa(const fc_paconv& e, int B, int M, void* ws, size_t bytes, bool dry, size_t* need) {
@@ -178,6 +179,7 @@ static PaWs plan_pa(const fc_paconv& e, int B, int M, void* ws, size_t bytes, bo
     }
     w.fidx = (int32_t*)c.bytes((size_t)B * std::max(w.n[1], 1) * sizeof(int32_t));
     w.nidx = (int32_t*)c.bytes(edges_max * sizeof(int32_t));
+    w.fps_tmp = fps_scratch_floats(B, M) ? c.floats(fps_scratch_floats(B, M)) : nullptr;     // > 8192 points per scene: global min-distance array
     w.gdiff = c.floats(edges_max * 4);
     w.scores = c.floats(edges_max * 8);
     w.Ea = c.floats(emax);
@@ -208,7 +210,7 @@ static void paconv_forward(fc_paconv& e, const float* pts, float* out, int B, in
     // ---- set abstraction
     for (int l = 0; l < 4; ++l) {
         const int n = w.n[l], m = w.n[l + 1], edges = B * m * K, edges_pad = round_up(std::max(edges, 1), ROW_PAD);
-        launch_fps(w.xyz[l], 4, w.fidx, B, n, m, s);
+        launch_fps(w.xyz[l], 4, w.fidx, B, n, m, w.fps_tmp, s);
         launch_gather_xyz(w.xyz[l], 4, w.fidx, w.xyz[l + 1], B, n, m, s);
         launch_knn_xyz(w.xyz[l], 4, w.xyz[l + 1], w.nidx, B, n, m, K, s);
         float* Ein = w.Ea;
@@ -304,7 +306,14 @@ int fc_paconv_embed_f32(fc_paconv* emb, const float* pts, float* out, int32_t B,
 int fc_op_fps_f32(const float* xyz, int32_t* idx, int32_t B, int32_t n, int32_t m, void* stream) {
     FC_API_BEGIN
     if (!xyz || !idx || B < 1 || n < 1 || m < 0) throw fc::Error(FC_ERR_INVALID, "fc_op_fps_f32: bad argument");
-    fc::launch_fps(xyz, 3, idx, B, n, m, (hipStream_t)stream);
+    /* (single-operator entry of the test / training paths: the one scratch array of the > 8192-point variant is allocated here, stream-ordered;
+     * the engine's own calls carve it from the caller's workspace) */
+    float* scratch = nullptr;
+    const size_t nf = fc::fps_scratch_floats(B, n);
+    if (nf) FC_HIP(hipMallocAsync((void**)&scratch, nf * sizeof(float), (hipStream_t)stream));
+    try { fc::launch_fps(xyz, 3, idx, B, n, m, scratch, (hipStream_t)stream); }
+    catch (...) { if (scratch) (void)hipFreeAsync(scratch, (hipStream_t)stream); throw; }
+    if (scratch) FC_HIP(hipFreeAsync(scratch, (hipStream_t)stream));
     FC_API_END
 }
 
