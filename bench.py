@@ -90,6 +90,46 @@ def cpu_baseline(cfg, md, points, seed):
                       f"{dt:.1f} s of host time"}, lp
 
 
+def train_main(args, cfg, md, batch, eps, dist, world, rank, dev):
+    """bench.py --train: W warm-up + K timed training steps per rank on its own scenes (weak scaling), barrier + synchronize on both sides,
+    MAX over ranks; the one exchange step is the bucketed RCCL SUM all-reduce of the gradients (flowcompare_amd/shard.py)."""
+    md["flow"].train()
+    md["input_embedder"].train()
+    params = [p for p in md["parameters"] if p.requires_grad]
+    reducer = shard.GradientReducer(params)
+    opt = torch.optim.Adam(reducer.params, lr=1e-5)
+    B, N = batch[1].shape[0], batch[1].shape[1]
+    n_global = world * B * N
+    loss = None
+    for i in range(args.warmup):
+        loss, lp, bpd, norm = shard.local_training_step(batch, n_global, md, cfg, reducer, optimizer=opt, eps=eps)
+        torch.cuda.synchronize()
+        log(f"rank {rank}: training warmup step {i}: loss {float(loss):.4f} |grad| {float(norm):.3e} peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, lp, bpd, norm = shard.local_training_step(batch, n_global, md, cfg, reducer, optimizer=opt, eps=eps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor(dt, device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    if rank == 0:
+        n_par = sum(p.numel() for p in reducer.params)
+        print(json.dumps({
+            "metric": "points/sec (training step: forward + backward + RCCL gradient all-reduce + clip + Adam)", "value": n_global * args.steps / dt,
+            "unit": "points/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16x2 split (fp32-equivalent operands, f32 accumulate) / f32",
+            "data": "synthetic (conditioned random-init weights)",
+            "config": {"workload": f"{args.config}: batch {B} scenes/GPU x {N} target + {N} context points, {cfg['n_flow_layers']} flow layers, embedder trained",
+                       "global_batch": world * B, "points_per_scene": N,
+                       "parallelism": f"scene-sharded x{world}; gradient all-reduce: {len(reducer.buckets)} buckets over {n_par * 4 / 2**20:.0f} MiB (RCCL)"},
+            "loss": float(loss), "grad_norm": float(norm), "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +143,10 @@ def main():
                     help="conditioned (default): module init + flowcompare_amd.conditioning.condition_flow (near-identity coupling output layers, "
                          "LinearLU mixing, ActNorm first-batch statistics) -- the state the full-depth parity tests gate at 1e-4 bpd; "
                          "module: the constructors' init as it is (ill-conditioned at 115 layers: diagnostic only)")
+    ap.add_argument("--train", action="store_true",
+                    help="time the TRAINING step instead (SURVEY.md 8f N1): forward + backward on the HIP training kernels, bucketed RCCL "
+                         "gradient all-reduce overlapped with backward, clip_grad_norm_, Adam; embedder in train() mode.  Prints its own JSON line "
+                         "(metric 'points/sec (training step ...)'); the default forward metric is BASELINE.json's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: leave the in-library HIP-event profiler off in the timed region")
     ap.add_argument("--knob", action="append", default=[], help="K=V tuning knob for same-box A/B runs (fc_debug_set); not for headline numbers")
@@ -127,6 +171,11 @@ def main():
     if world > 1 or "RANK" in os.environ:             # under torch.distributed.run (also with one rank: exercises the RCCL path)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+    elif args.train:                                  # the training step's exchange is RCCL's also on one GPU (a one-rank group)
+        import socket
+        import torch.distributed as dist
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     over = {"sample_size": args.points}
     if args.layers:
@@ -150,6 +199,9 @@ def main():
     e0, e1, extra, g = synth_pairs(B, N, N, 1000 + rank, dev)   # every rank owns different scenes
     batch = (e0, e1, extra if cfg["extra_z_value_context"] else None)
     eps = [torch.randn(B, N, cfg["latent_dim"] - cfg["input_dim"], generator=g).to(dev)]
+
+    if args.train:
+        return train_main(args, cfg, md, batch, eps, dist, world, rank, dev)
 
     def step():
         loss, lp, bpd = fa.inner_loop(batch, md, cfg, eps=eps)

@@ -183,7 +183,18 @@ def local_loss(log_prob_local, n_global_points):
 def sharded_training_step(batch, models_dict, config, reducer, optimizer=None, eps=None, grad_clip=None, group=None):
     """train.py:108-120 over a GLOBAL batch sharded by scenes: every rank differentiates its scenes through the HIP training path,
     gradients are summed by `reducer` (bucketed, overlapped with backward), then clip_grad_norm_ / optimizer.step() run identically
-    on every rank.  Returns (global loss, local log_prob, global bpd, grad_norm).
+    on every rank.  Returns (global loss, local log_prob, global bpd, grad_norm).  See local_training_step for the first-batch rules."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_bounds(batch[0].shape[0], rank, world)
+    local = shard_batch(batch, rank, world)
+    eps_local = None if eps is None else [e[lo:hi] for e in eps]
+    n_global = batch[1].shape[0] * batch[1].shape[1]
+    return local_training_step(local, n_global, models_dict, config, reducer, optimizer, eps_local, grad_clip, group)
+
+
+def local_training_step(local, n_global_points, models_dict, config, reducer, optimizer=None, eps=None, grad_clip=None, group=None):
+    """The sharded step on THIS rank's scenes `local` = (extract_0, extract_1, extra_context) of a global batch with `n_global_points`
+    target points in total (what sharded_training_step calls after slicing; bench.py --train calls it directly with rank-local scenes).
 
     First batch: ActNorm's data-dependent initialisation (act_norm.py:27-39) takes the statistics of the GLOBAL batch (column sums
     all-reduced over the group) and writes them IN PLACE, so every rank holds the same ActNorm weights and the reducer / optimizer keep
@@ -193,11 +204,6 @@ def sharded_training_step(batch, models_dict, config, reducer, optimizer=None, e
     from .model_initialization import inner_loop
     from . import train_flow
     from . import train_ops as T
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    lo, hi = shard_bounds(batch[0].shape[0], rank, world)
-    local = shard_batch(batch, rank, world)
-    eps_local = None if eps is None else [e[lo:hi] for e in eps]
-    n_global = batch[1].shape[0] * batch[1].shape[1]
     params = reducer.params
     attempts = train_flow.step_attempts(models_dict)
     snap = train_flow.snapshot_step_state(models_dict)
@@ -206,8 +212,8 @@ def sharded_training_step(batch, models_dict, config, reducer, optimizer=None, e
             train_flow.restore_step_state(models_dict, snap)
         reducer.zero_grad()
         with T.step_guard(fp16=fp16, device=local[1].device) as guard, train_flow.actnorm_init_mode(in_place=True, group=group or True):
-            _, lp, _ = inner_loop(local, models_dict, config, eps=eps_local)
-            local_loss(lp, n_global).backward()
+            _, lp, _ = inner_loop(local, models_dict, config, eps=eps)
+            local_loss(lp, n_global_points).backward()
             over = torch.tensor([1.0 if guard.overflowed() else 0.0], device=lp.device)
         reducer.finish()
         dist.all_reduce(over, group=group)                   # every rank repeats the step if ANY rank left the fp16 range

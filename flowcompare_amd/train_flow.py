@@ -60,7 +60,9 @@ def _perm_weight(perm, cfg):
         iu = torch.triu_indices(D, D, 1, device=dev)
         L = torch.eye(D, device=dev, dtype=diag.dtype).index_put((il[0], il[1]), perm.lower_entries)
         U = torch.diag(diag).index_put((iu[0], iu[1]), perm.upper_entries)
-        return L @ U, torch.log(diag).sum()
+        # L U on the library's own training Linear (y = x W^T with x = L, W = U^T): no vendor BLAS on the training path
+        LU = T.from_panel(T.linear_act([T.to_panel(L)], [D], U.t(), None, D), D, D)
+        return LU, torch.log(diag).sum()
     if isinstance(perm, M.Permuter):
         D = perm.permutation.numel()
         return torch.eye(D, device=perm.permutation.device)[perm.permutation.long()], torch.zeros((), device=perm.permutation.device)
@@ -245,7 +247,10 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
                 logp = logp - an.log_scale.sum()
             if perm is not None:
                 Wlu, logdet = _perm_weight(perm, cfg)
-                W, b = (Wlu, None) if W is None else (Wlu @ W, Wlu @ b)
+                if W is None:
+                    W, b = Wlu, None
+                else:                                         # Wlu diag(g) and Wlu b: a column scaling and a row reduction (parameter space), no GEMM
+                    W, b = Wlu * g[None, :], (Wlu * b[None, :]).sum(1)
                 logp = logp + logdet
             if W is not None:
                 z1 = T.linear_act([x1, x2], [d1, d2], W[:d1], None if b is None else b[:d1], rows)

@@ -298,3 +298,33 @@ def test_cif_stack_at_real_layer_widths_matches_the_oracle():
     rt = (xr.cpu().double() - x_o).abs().max().item() / max(1.0, x_o.abs().max().item())
     print(f"CIF real widths: inverse vs oracle, max relative to |x|max {rt:.2e}")
     assert rt < 5e-4
+
+
+def test_parameter_change_triggers_a_fast_repack():
+    """Evaluating between optimiser steps (train.py:134-170): any in-place parameter change re-packs the engine on the next call (folding on
+    a pool of host threads, limb images made on the device).  The changed weight must take effect, restoring it must reproduce the
+    first result bit for bit, and a re-pack of this 8-layer spline flow at the real widths must stay far below a second."""
+    import time
+    cfg = fa.named_config("c2_dgcnn_attn_spline", n_flow_layers=8, sample_size=200)
+    torch.manual_seed(3)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    g = torch.Generator().manual_seed(4)
+    e0, e1 = torch.rand(2, 256, 6, generator=g).to(DEV), torch.rand(2, 200, 6, generator=g).to(DEV)
+    eps = [torch.randn(2, 200, 294, generator=g).to(DEV)]
+    _, lp0, _ = fa.inner_loop((e0, e1, None), md, cfg, eps=eps)
+    w = md["flow"].transforms[4].transform.nn.layers[0].weight
+    with torch.no_grad():
+        saved = w[3, 5].clone()
+        w[3, 5] += 0.5
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, lp1, _ = fa.inner_loop((e0, e1, None), md, cfg, eps=eps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert not torch.equal(lp0, lp1)
+    with torch.no_grad():
+        w[3, 5] = saved
+    _, lp2, _ = fa.inner_loop((e0, e1, None), md, cfg, eps=eps)
+    assert torch.equal(lp0, lp2)
+    print(f"re-pack + forward of an 8-layer spline flow after a parameter change: {dt * 1e3:.0f} ms")
+    assert dt < 1.0
