@@ -32,11 +32,12 @@ import flowcompare_amd as fa  # noqa: E402
 from flowcompare_amd import engine, shard  # noqa: E402
 
 # SURVEY.md §8(d) / BASELINE.md §4: algorithmic MFLOP per target point (1 MAC = 2 FLOP), by config
-ALG_MFLOP_PER_POINT = {"c1_dgcnn_global_affine": 396.0, "c2_dgcnn_attn_spline": 859.0, "c4_dgcnn_attn_extra_affine": 453.0}
+ALG_MFLOP_PER_POINT = {("c1_dgcnn_global_affine", 1024): 396.0, ("c2_dgcnn_attn_spline", 4096): 859.0, ("c4_dgcnn_attn_extra_affine", 4096): 453.0,
+                       ("c4_dgcnn_attn_extra_affine", 16384): 824.0}      # (config, points per scene): C1, C2, C4, C5
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MATRIX_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse headline)
 PEAK_HBM_GBS = 8000.0
-SPLIT_MFMA_PER_PRODUCT = {5: 3, 7: 3, 3: 6}   # gemm.hip: the split-fp16 loops (VAR 5; VAR 7 = A operand pre-split) issue 3 fp16 MFMAs per fp32-equivalent product block, the
+SPLIT_MFMA_PER_PRODUCT = {5: 3, 7: 3, 8: 3, 3: 6}   # gemm.hip: the split-fp16 loops (VAR 5; VAR 7 = A operand pre-split) issue 3 fp16 MFMAs per fp32-equivalent product block, the
                                         # split-bf16 loop (VAR 3, its fallback) 6 bf16 MFMAs; both run at the 2500 TFLOP/s dense 16-bit rate
 
 
@@ -265,10 +266,12 @@ def main():
         if dom["flops"] > 0:
             useful = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12          # fp32-equivalent multiply-add TFLOP/s
             var = next((v for v in SPLIT_MFMA_PER_PRODUCT if dom["kernel"].endswith(f", {v}>(fc::GemmParams)")), None)   # ..., VAR>
+            if var is None and "attn16_kernel" in dom["kernel"]:
+                var = 5                                     # split-fp16 attention: 3 limb products per fp32-equivalent product in QK^T and in PV
             if var is not None:
                 n = SPLIT_MFMA_PER_PRODUCT[var]
                 achieved, peak = useful * n, PEAK_BF16_MATRIX_TFLOPS
-                note = (f"split-{'fp16' if var in (5, 7) else 'bf16'} loop: achieved = 16-bit MFMA FLOPs actually issued ({n} limb products per "
+                note = (f"split-{'fp16' if var in (5, 7, 8) else 'bf16'} loop: achieved = 16-bit MFMA FLOPs actually issued ({n} limb products per "
                         "fp32-equivalent product, padding excluded) against the dense fp16/bf16 MFMA peak 2500 TFLOP/s; "
                         "useful_fp32_equivalent_tflops is the same launch time priced in fp32-equivalent FLOPs (the fp32-input MFMA "
                         "peak is 157.3 TFLOP/s)")
@@ -286,15 +289,19 @@ def main():
         # HBM bytes per launch of that kernel from the committed PMC passes of this same command (profiles/pmc_summary.py: separate
         # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction); PMC cannot be collected inside a timed run
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"].get(dom["kernel"])
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pmc = pj["kernels"].get(dom["kernel"])
             if pmc and args.config == "c2_dgcnn_attn_spline" and B == 16 and N == 4096 and not args.layers:
                 roof["traffic"] = pmc["hbm_bytes_per_launch"]
-                roof["traffic_unit"] = "HBM bytes per launch (profiles/pmc_traffic.json)"
+                meas = pj.get("measured", {})
+                roof["traffic_unit"] = ("HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                        f"(profiles/pmc_traffic.json, measured {meas.get('date', '?')} on build {meas.get('label', '?')}; counters cannot be "
+                                        "collected inside a timed run)")
         except (OSError, KeyError, ValueError):
             pass
         roof.update({"avg_launch_ms": per_launch_ms, "launches": dom["launches"], "share_of_gpu_time": dom["ms"] / tot_ms,
                      "flops_counted": "useful multiply-adds of the launches (padding excluded), HIP events on the launch stream"})
-        alg = ALG_MFLOP_PER_POINT.get(args.config)
+        alg = ALG_MFLOP_PER_POINT.get((args.config, N))
         out = {
             "metric": "nats/sec (forward log-prob) on 4096-pt coloured pairs", "value": value, "unit": "nats/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

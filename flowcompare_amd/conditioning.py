@@ -45,6 +45,7 @@ def condition_flow(models_dict, config, batch, eps=None, out_scale=0.1, lu_scale
     """In place on models_dict['flow'] (HIP device).  `batch` = (extract_0, extract_1, extra_context) as for inner_loop: the batch
     the ActNorm statistics are taken from (the embedder runs as it is, normally in eval mode).  Returns models_dict."""
     from . import train_flow
+    from . import train_ops as T
     flow, emb = models_dict["flow"], models_dict["input_embedder"]
     dev = next(flow.parameters()).device
     if dev.type != "cuda":
@@ -80,8 +81,15 @@ def condition_flow(models_dict, config, batch, eps=None, out_scale=0.1, lu_scale
         was_training = flow.training
         flow.train()
         try:
-            with train_flow.actnorm_init_mode(in_place=True):
-                train_flow.flow_log_prob(flow, e1, ctx, extra, eps, checkpoint=False)
+            # split-fp16 kernels first (the step's range flag decides), fp32-input kernels if an activation left the fp16 range
+            for fp16 in (True, False):
+                for t in flow.modules():
+                    if isinstance(t, M.ActNormBijectionCloud):
+                        t.initialized.zero_()
+                with T.step_guard(fp16=fp16, device=dev) as guard, train_flow.actnorm_init_mode(in_place=True):
+                    train_flow.flow_log_prob(flow, e1, ctx, extra, eps, checkpoint=False)
+                    if not guard.overflowed():
+                        break
         finally:
             flow.train(was_training)
         for t in flow.modules():
