@@ -127,6 +127,7 @@ struct GemmEpi {
     // EPI_LINEAR
     int act = FC_ACT_NONE;
     const float* residual = nullptr; int ldr = 0;
+    const unsigned short* residual16 = nullptr; int ldr16 = 0;   // the residual given as an fp16 limb image [rows][ldr16/16][hi 16 | lo' 16] (x = hi + lo'/2048)
     const float* rowscal = nullptr;          // [rows] (extra context per point), used with PackedLinear.colvec
     float* C = nullptr; int ldc = 0;          // may be null when only the limb image C16 is wanted
     unsigned short* C16 = nullptr;            // optional: the output as fp16 limb image [rows][N_pad/16][hi 16 | lo' 16] (operand image of a
@@ -178,6 +179,7 @@ struct Fp16FlagScope {
 };
 bool gemm_fp16_enabled();
 bool gemm_limb_chain_ok();
+bool gemm_limb_chain_all_ok();   // every hidden activation of a limb-chained MLP as a limb image (A16 in, C16 out, residual16)
 bool gemm_lnq_ok();             // the LayerNorm -> q fold (EPI_LNQ) can run: guard scope open, default tile
 void launch_lnq_finalize(float* q, int ldq, const float* sumsq, int nslots, size_t pitch, int width, const float* q_bias, int rows, hipStream_t s);      // inside a guard scope on the default tile: producers may emit / consumers may take limb images
 bool gemm_split_enabled();        // a split (limb) GEMM loop is the active variant: the fused spline epilogue is available

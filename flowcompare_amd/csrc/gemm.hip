@@ -127,6 +127,30 @@ void gemm_f32_kernel(const GemmParams p) {
                     for (int r = 0; r < 16; ++r) acc[i][j][r] += rs[i][r] * cv;
             }
         }
+        if (e.residual16) {
+            // residual from the limb image its producer wrote (hidden activations of a limb-chained MLP exist only in that form)
+            const int blocks = e.ldr16 >> 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (j < nvalid) {
+                    const int col = wave_n0 + j * 32 + li;
+                    const unsigned short* rp = e.residual16 + ((size_t)(wave_m0 + 4 * lh) * blocks + (col >> 4)) * 32 + (col & 15);
+                    unsigned short th[TM][16], tl[TM][16];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned short* q = rp + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * blocks * 32;
+                            th[i][r] = q[0]; tl[i][r] = q[16];
+                        }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[i][j][r] += (float)__builtin_bit_cast(_Float16, th[i][r]) + (float)__builtin_bit_cast(_Float16, tl[i][r]) * (1.0f / 2048.0f);
+                }
+            }
+        }
         if (e.residual) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -659,13 +683,14 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_lnq_fold = 1, g_fused_spline = 1, g_gemm_dma = 0, g_spline_ablate = 0;   // g_gemm_dma (knob 13): the LDS-DMA loop (VAR 8) for the fused spline GEMM -- bit-identical results, measured 2.6 % slower than VAR 7     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_lnq_fold = 1, g_fused_spline = 1, g_gemm_dma = 0, g_spline_ablate = 0, g_gemm_dma_linear = 1, g_limb_chain_all = 0;   // g_limb_chain_all (knob 16): every hidden activation of the coupling MLP as a limb image -- correct, 2 % slower end to end   // g_gemm_dma (knob 13): the LDS-DMA loop (VAR 8) for the fused spline GEMM -- bit-identical results, measured 2.6 % slower than VAR 7     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
 
 bool gemm_fp16_enabled() { return g_gemm_variant == 5; }
 bool gemm_lnq_ok() { return g_gemm_variant == 5 && t_fp16_flag != nullptr && g_gemm_bigtile == 3 && g_lnq_fold; }
+bool gemm_limb_chain_all_ok() { return g_gemm_variant == 5 && t_fp16_flag != nullptr && g_gemm_bigtile == 3 && g_fused_spline && g_limb_chain && g_limb_chain_all; }
 bool gemm_limb_chain_ok() { return g_gemm_variant == 5 && t_fp16_flag != nullptr && g_gemm_bigtile == 3 && g_fused_spline && g_limb_chain; }
 bool gemm_split_enabled() { return (g_gemm_variant == 5 || g_gemm_variant == 3) && g_fused_spline; }
 int* gemm_fp16_flag() { return g_gemm_variant == 5 ? t_fp16_flag : nullptr; }
@@ -738,7 +763,13 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         if ((!e.C && !e.C16) || (e.C && e.ldc < L.N_pad)) throw Error(FC_ERR_INVALID, "launch_gemm: output pitch smaller than N_pad");
         if (e.C16 && !(f16 && g_gemm_bigtile == 3 && L.N_pad > 64 && L.N_pad % 16 == 0))
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: limb-image output exists on the eight-wave split-fp16 tile only");
-        if (L.N_pad <= 64) {
+        if (e.A16) {
+            // A arrives as the limb image of the producing layer (limb-chained MLP): the copy-only main loops
+            if (!(f16 && g_gemm_bigtile == 3 && L.nseg == 1 && L.N_pad > 64 && L.n_alloc >= round_up(L.N_pad, 128)))
+                throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: a limb-image A operand needs the split-fp16 loop, one segment and N > 64");
+            if (g_gemm_dma_linear && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 8>(p, s); }
+            else { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 4, 2, EPI_LINEAR, 7>(p, s); }
+        } else if (L.N_pad <= 64) {
             p.nbm = rows_alloc / 128;
             if (f16) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 5>(p, s);
             else if (split) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 3>(p, s);
