@@ -183,7 +183,7 @@ void gemm_f32_kernel(const GemmParams p) {
         //   ({0-3,12-15,20-27}, ...) then hit 16 distinct 16-byte slots.  The DMA writes LDS linearly (wave base + lane * 16), so the
         //   permutation is applied to the per-lane SOURCE address and again on the read (same involution on both sides).
         static_assert(BM == 256 && BN == 128 && WM == 4 && WN == 2, "LDS-DMA loop: written for the 256x128 tile on 4x2 waves");
-        constexpr int ROWB8 = 128, STAGE8 = (BM + BN) * ROWB8, NST = 3;
+        constexpr int ROWB8 = 128, STAGE8 = (BM + BN) * ROWB8;        // three stages (launch_cfg reserves 3 * STAGE8)
         constexpr int PPW = STAGE8 / 1024 / (NT / 64);                       // 1-KB DMA pieces per wave and stage: 6
         typedef __attribute__((address_space(3))) char lds_char;
         typedef const __attribute__((address_space(1))) char glb_char;
@@ -297,12 +297,12 @@ void gemm_f32_kernel(const GemmParams p) {
         float amax = 0.f;
         // two register sets: the tile loaded in iteration kt is only converted/stored in iteration kt+1, so a global load has a
         // whole iteration (the MFMAs of the other resident waves included) to land before anything waits for it
-        float4 ra3_0[A3], ra3_1[A3];
+        float4 ra3_0[A3], ra3_1[A3], ra3_2[A3];            // (set 2: VAR 6 only, dead otherwise)
         constexpr int A4N = (BM * CH + NT - 1) / NT;                // 16-byte chunks of the A limb image per thread and stage
         typedef unsigned int u32xa __attribute__((ext_vector_type(4 * A4N)));
-        u32xa ra4_0, ra4_1;
+        u32xa ra4_0, ra4_1, ra4_2;
         typedef unsigned int u32xw __attribute__((ext_vector_type(4 * W3N)));      // whole-vector values: never an alloca, so never scratch
-        u32xw rw3_0, rw3_1;
+        u32xw rw3_0, rw3_1, rw3_2;
 #define FC_GLOAD3(S_, KT_)                                                                                           \
         {                                                                                                          \
             const float* Ap_ = p.A[0];                                                                             \
@@ -417,6 +417,40 @@ void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) corr[i][j][r] = 0.f;
         }
+        if constexpr (VAR == 6) {
+            // THREE register sets: a tile's global loads are issued three stages before its MFMAs (two in registers, one in LDS).  The
+            // Linear launches of the flow stream their A operand from HBM / Infinity Cache once (no column-tile reuse to speak of at
+            // N <= 512), 64 KB in flight per CU did not cover that latency (SQ_WAIT_ANY 43 % of the wave cycles at 25 % matrix-pipe busy).
+            // LDS stays double-buffered: stage (kt + 1) & 1 was last read in iteration kt - 1, one barrier back.
+            FC_GLOAD3(0, 0)
+            FC_GLOAD3(1, (1 < KT16 ? 1 : KT16 - 1))
+            FC_GLOAD3(2, (2 < KT16 ? 2 : KT16 - 1))
+            FC_LSTORE3(0, 0)
+            __syncthreads();
+            int par = 0;
+            for (int kt = 0; kt < KT16; kt += 3) {
+                const int k3 = kt + 3 < KT16 ? kt + 3 : KT16 - 1, k4 = kt + 4 < KT16 ? kt + 4 : KT16 - 1, k5 = kt + 5 < KT16 ? kt + 5 : KT16 - 1;
+                FC_GLOAD3(0, k3)
+                FC_MMA3(par)
+                FC_LSTORE3(1, (par ^ 1))
+                __syncthreads();
+                par ^= 1;
+                if (kt + 1 < KT16) {
+                    FC_GLOAD3(1, k4)
+                    FC_MMA3(par)
+                    FC_LSTORE3(2, (par ^ 1))
+                    __syncthreads();
+                    par ^= 1;
+                }
+                if (kt + 2 < KT16) {
+                    FC_GLOAD3(2, k5)
+                    FC_MMA3(par)
+                    FC_LSTORE3(0, (par ^ 1))
+                    __syncthreads();
+                    par ^= 1;
+                }
+            }
+        } else {
         // KT16 is even (K_pad is a multiple of 32).  Stage s of LDS holds tile kt (s = kt & 1); register set s holds tile kt+1 ... kt+2.
         FC_GLOAD3(0, 0)
         FC_LSTORE3(0, 0)
@@ -432,6 +466,7 @@ void gemm_f32_kernel(const GemmParams p) {
             FC_MMA3(1)
             FC_LSTORE3(0, 0)
             __syncthreads();
+        }
         }
         if constexpr (F16) {
 #pragma unroll
@@ -683,7 +718,7 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_lnq_fold = 1, g_fused_spline = 1, g_gemm_dma = 0, g_spline_ablate = 0, g_gemm_dma_linear = 1, g_limb_chain_all = 0;   // g_limb_chain_all (knob 16): every hidden activation of the coupling MLP as a limb image -- correct, 2 % slower end to end   // g_gemm_dma (knob 13): the LDS-DMA loop (VAR 8) for the fused spline GEMM -- bit-identical results, measured 2.6 % slower than VAR 7     // tuning knobs (fc_debug_set), defaults = shipped configuration
+int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_lnq_fold = 1, g_fused_spline = 1, g_gemm_dma = 0, g_spline_ablate = 0, g_gemm_dma_linear = 1, g_limb_chain_all = 0, g_gemm_prefetch3 = 0;   // g_gemm_prefetch3 (knob 17): VAR 6, bit-identical, measured 3.5 % slower on the Linear family   // g_limb_chain_all (knob 16): every hidden activation of the coupling MLP as a limb image -- correct, 2 % slower end to end   // g_gemm_dma (knob 13): the LDS-DMA loop (VAR 8) for the fused spline GEMM -- bit-identical results, measured 2.6 % slower than VAR 7     // tuning knobs (fc_debug_set), defaults = shipped configuration
 
 static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
@@ -714,7 +749,7 @@ bool Fp16Guard::overflowed() {
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 6 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
     constexpr size_t lds_epi = EPI == EPI_SPLINE ? ((size_t)BM * (BN + 1) + (size_t)BM * 9) * sizeof(float) : 0;   // tile + <= 9 dims of log-dets
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
@@ -785,7 +820,8 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             else if (split && g_gemm_bigtile == 2 && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 3>(p, s); }
             else {
                 p.nbm = rows_alloc / 128;
-                if (f16 && g_gemm_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_LINEAR, 5>(p, s);
+                if (f16 && g_gemm_bigtile == 3 && g_gemm_prefetch3) launch_cfg<128, 128, 4, 2, EPI_LINEAR, 6>(p, s);
+                else if (f16 && g_gemm_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_LINEAR, 5>(p, s);
                 else if (f16) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 5>(p, s);
                 else if (split) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 3>(p, s);
                 else if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);

@@ -208,7 +208,7 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
     eps = [torch.randn(B, N, 294, generator=g).to(DEV)]
     batch = (e0.to(DEV), e1.to(DEV), None)
-    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 0, 9: 1, 10: 1, 13: 0, 15: 1, 16: 0}
+    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 0, 9: 1, 10: 1, 13: 0, 15: 1, 16: 0, 17: 0}
     try:
         _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
         for name, knobs in (("unfused spline", {7: 0}), ("fused pre-attention chain kernel", {8: 1}), ("separate LayerNorm + q projection", {10: 0}), ("no limb chain", {9: 0}), ("every hidden activation as a limb image, LDS-DMA loop", {16: 1}), ("every hidden activation as a limb image, register-staged tile", {16: 1, 15: 0}), ("fp32-input attention", {5: 0}),
@@ -227,6 +227,10 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
         _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
         lib.fc_debug_set(13, 0)
         assert torch.equal(lp, ref), "LDS-DMA spline GEMM differs from the register-staged loop"
+        lib.fc_debug_set(17, 1)                                   # three register sets of prefetch instead of two: same MFMAs, same order
+        _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+        lib.fc_debug_set(17, 0)
+        assert torch.equal(lp, ref), "prefetch depth changed the Linear GEMM's results"
     finally:
         for k, v in defaults.items():
             lib.fc_debug_set(k, v)
