@@ -38,6 +38,7 @@ EXPORTS = [
     "fc_train_edge_ws_bytes", "fc_train_edge_stats_f32", "fc_train_edge_fwd_f32", "fc_train_edge_bwd_prep_f32", "fc_train_edge_bwd_scatter_f32", "fc_train_edge_bwd_gather_f32", "fc_train_pool_fwd_f32", "fc_train_pool_bwd_f32",
     "fc_op_paconv_knn_f32", "fc_train_paconv_group_f32", "fc_train_softmax_fwd_f32", "fc_train_softmax_bwd_f32", "fc_train_assign_fwd_f32", "fc_train_assign_bwd_f32",
     "fc_train_centerdiff_fwd_f32", "fc_train_centerdiff_bwd_f32", "fc_train_rows_gather_bwd_f32", "fc_train_three_nn_f32", "fc_train_interp_fwd_f32",
+    "fc_train_sqnorm_ws_bytes", "fc_train_sqnorm_f32", "fc_train_adam_f32",
 ]
 
 
@@ -78,6 +79,7 @@ def lib():
         L.fc_train_attention_ws_bytes.restype = ctypes.c_size_t
         L.fc_train_colsum_ws_bytes.restype = ctypes.c_size_t
         L.fc_train_edge_ws_bytes.restype = ctypes.c_size_t
+        L.fc_train_sqnorm_ws_bytes.restype = ctypes.c_size_t
         if L.fc_abi_version() != ABI_VERSION:
             raise RuntimeError("libfcflow.so ABI version mismatch: rebuild with `python -m flowcompare_amd.build --force`")
         _lib = L

@@ -159,6 +159,85 @@ class GradientReducer:
             h.remove()
 
 
+class FlatAdam:
+    """clip_grad_norm_ + torch.optim.Adam.step (train.py:112-120) as HIP kernels on the reducer's flat gradient buffers: the Adam moments
+    mirror the bucket layout, the parameters are reached through a device pointer table, one launch per bucket (csrc/train_optim.hip)
+    instead of torch's foreach kernels over ~3000 tensors.  Semantics of torch.optim.Adam(amsgrad=False): L2 weight decay added to the
+    gradient, bias corrections 1 - beta^t.  The clip coefficient min(1, max_norm / (norm + 1e-6)) stays on the device between the norm
+    and the update.  Difference to torch: a parameter whose `.grad` is None after `reducer.finish()` (no gradient on any rank) is not
+    skipped but sees the zero slice of its bucket -- its moments decay and weight decay still applies; on this path every parameter of
+    the flow and of a trained embedder receives a gradient every step."""
+
+    def __init__(self, reducer, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        import ctypes
+        from . import engine
+        self.reducer = reducer
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.t = 0
+        dev = reducer.flat[0].device
+        if dev.type != "cuda" or reducer.flat[0].dtype != torch.float32:
+            raise RuntimeError("FlatAdam: fp32 parameters on a HIP device (there is no CPU path)")
+        self.m = [torch.zeros_like(f) for f in reducer.flat]
+        self.v = [torch.zeros_like(f) for f in reducer.flat]
+        self.tables = []
+        chunk = 4096
+        for b in reducer.buckets:
+            for p in b:
+                if not p.is_contiguous():
+                    raise RuntimeError("FlatAdam: parameters must be contiguous")
+            ptrs = torch.tensor([p.data_ptr() for p in b], dtype=torch.int64, device=dev)
+            sizes = [p.numel() for p in b]
+            offs = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0).tolist()), dtype=torch.int64, device=dev)
+            ct, co = [], []
+            for i, n in enumerate(sizes):
+                for o in range(0, n, chunk):
+                    ct.append(i)
+                    co.append(o)
+            self.tables.append((ptrs, offs, torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(co, dtype=torch.int64, device=dev), len(ct)))
+        L = engine.lib()
+        nb = max(L.fc_train_sqnorm_ws_bytes(ctypes.c_int64(f.numel())) for f in reducer.flat)
+        self.ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        self.sq = torch.zeros(len(reducer.flat), dtype=torch.float64, device=dev)
+        self.coef = torch.ones(1, dtype=torch.float32, device=dev)
+
+    def step(self, max_norm=None):
+        """Global-norm clip (optional) + Adam update; returns the gradient norm (device scalar, before clipping)."""
+        import ctypes
+        from . import engine
+        L = engine.lib()
+        r = self.reducer
+        dev = r.flat[0].device
+        self.t += 1
+        with torch.cuda.device(dev):
+            s = engine._stream()
+            for i, f in enumerate(r.flat):
+                engine._check(L.fc_train_sqnorm_f32(engine._ptr(f), ctypes.c_int64(f.numel()), engine._ptr(self.sq), i, engine._ptr(self.ws),
+                                                    ctypes.c_size_t(self.ws.numel()), s))
+            norm = self.sq.sum().sqrt()                                           # parameter-sized: 39 numbers
+            if max_norm:
+                self.coef.copy_((max_norm / (norm + 1e-6)).clamp(max=1.0).to(torch.float32).reshape(1))
+            for i, f in enumerate(r.flat):
+                ptrs, offs, ct, co, n_chunks = self.tables[i]
+                engine._check(L.fc_train_adam_f32(engine._ptr(ptrs), engine._ptr(offs), engine._ptr(ct), engine._ptr(co), n_chunks, engine._ptr(f),
+                                                  engine._ptr(self.m[i]), engine._ptr(self.v[i]), engine._ptr(self.coef) if max_norm else ctypes.c_void_p(0),
+                                                  ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
+                                                  ctypes.c_float(self.eps), ctypes.c_float(self.weight_decay), self.t, s))
+        return norm.to(torch.float32)
+
+    def state_dict(self):
+        """torch.optim.Adam's checkpoint layout (save_flow stores optimizer.state_dict(), model_initialization.py:25-28): per-parameter
+        exp_avg / exp_avg_sq are views of the flat moment buffers, parameter order = reducer.params."""
+        state = {}
+        for j, p in enumerate(self.reducer.params):
+            i = self.reducer.bucket_of[id(p)]
+            v = self.reducer.views[id(p)]
+            off = (v.data_ptr() - self.reducer.flat[i].data_ptr()) // 4
+            n = p.numel()
+            state[j] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[i][off:off + n].view_as(p), "exp_avg_sq": self.v[i][off:off + n].view_as(p)}
+        return {"state": state, "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                                                  "params": list(range(len(self.reducer.params)))}]}
+
+
 def sync_batchnorm_buffers(module, group=None):
     """Train-mode BatchNorm running statistics are per shard, as in the reference's nn.DataParallel (no SyncBN): every
     rank updates them from its own scenes.  Averaging them over the ranks after a step keeps the replicas' eval-mode behaviour and
@@ -222,6 +301,9 @@ def local_training_step(local, n_global_points, models_dict, config, reducer, op
     sync_batchnorm_buffers(models_dict["input_embedder"], group)
     loss, bpd = global_loss_bpd(lp.detach(), config["input_dim"], group)
     clip = config.get("grad_clip_val") if grad_clip is None else grad_clip
+    if isinstance(optimizer, FlatAdam):                      # native clip + Adam on the flat buffers (csrc/train_optim.hip)
+        norm = optimizer.step(max_norm=clip if clip else None)
+        return loss, lp.detach(), bpd, norm
     norm = torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], max_norm=clip if clip else float("inf"))
     if optimizer is not None:
         optimizer.step()

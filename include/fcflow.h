@@ -18,7 +18,8 @@
  * 3 = + the stateless training primitives fc_train_* (forward AND backward of every node of the path, no handles: parameters stay
  *     the caller's dense fp32 device tensors because they change every optimiser step);
  * 4 = + the PAConv embedder's training primitives (softmax / assign_score / centre difference / gathered-row gradients / 3-NN
- *     interpolation), LeakyReLU slope argument of fc_train_edge_fwd_f32 / fc_train_edge_bwd_prep_f32 (0 = ReLU).
+ *     interpolation), LeakyReLU slope argument of fc_train_edge_fwd_f32 / fc_train_edge_bwd_prep_f32 (0 = ReLU), optimiser step
+ *     (fc_train_sqnorm_f32, fc_train_adam_f32).
  */
 #ifndef FCFLOW_H
 #define FCFLOW_H
@@ -331,6 +332,12 @@ int fc_train_rows_gather_bwd_f32(const float* dout, int32_t ldo, int32_t col0, i
 int fc_train_three_nn_f32(const float* uxyz, const float* kxyz, int32_t B, int32_t nu, int32_t mk, int32_t* idx, float* w, void* stream);
 int fc_train_interp_fwd_f32(const float* Fk, int32_t ldfk, int32_t C, const int32_t* idx, const float* w, int32_t rows, int32_t rows_pad, float* out,
                             int32_t ldo, void* stream);
+
+/* ---- optimiser step on flat gradient buffers (train.py:112-120: clip_grad_norm_ + Adam.step; flowcompare_amd/shard.py FlatAdam) */
+size_t fc_train_sqnorm_ws_bytes(int64_t n);
+int fc_train_sqnorm_f32(const float* g, int64_t n, double* out, int32_t slot, void* ws, size_t ws_bytes, void* stream);
+int fc_train_adam_f32(float* const* params, const int64_t* offsets, const int32_t* chunk_tensor, const int64_t* chunk_off, int32_t n_chunks, const float* g,
+                      float* m, float* v, const float* coef, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, void* stream);
 
 #ifdef __cplusplus
 }

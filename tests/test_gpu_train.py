@@ -689,23 +689,15 @@ def test_two_rank_first_batch_actnorm_init_uses_global_statistics_and_keeps_para
 
 @pytest.mark.timeout(900)
 def test_sharded_training_step_over_rccl():
-    """The same sharded step with backend "nccl" (= RCCL): one rank always (the collectives, the flat gradient views and the stream
-    ordering are RCCL's); two ranks sharing the one card when RCCL accepts that (it normally refuses duplicate devices -- then the
-    two-rank RCCL run is left to the 8-GPU node and this test says so)."""
+    """The same sharded step with backend "nccl" (= RCCL) and one rank: the collectives, the flat gradient views and the stream ordering
+    are RCCL's (first-batch ActNorm init with all-reduced statistics, bucketed gradient all-reduce, presence mask, Adam step)."""
     res, codes = _spawn(_sharded_init_worker, 1, "nccl")
     assert codes == [0] and res[0][2]
     z = np.load(os.path.join(GOLDEN, "grad_tiny_affine.npz"))
     assert abs(res[0][1] - float(z["init/loss"])) < 2e-4 * max(1.0, abs(float(z["init/loss"])))
-    try:
-        res2, codes2 = _spawn(_sharded_init_worker, 2, "nccl", timeout=180)
-    except Exception as e:                                        # queue.Empty: a rank died in init_process_group / the first collective
-        print(f"RCCL with two ranks on ONE device is not possible on this box ({type(e).__name__}); one-rank RCCL run passed")
-        return
-    if codes2 != [0, 0]:
-        print(f"RCCL with two ranks on ONE device failed (exit codes {codes2}); one-rank RCCL run passed")
-        return
-    assert res2[0][4] == res2[1][4]
-    print("RCCL with two ranks sharing one device: identical replicas after the first-batch init and an Adam step")
+    # Two RCCL ranks on ONE device: tried on this pool (round 2) -- init_process_group hangs until the timeout, RCCL does not share a
+    # device between ranks -- so the two-rank runs of the same code use gloo (the two tests above) and RCCL with > 1 rank is left to the
+    # driver's 8-GPU node (bench.py --gpus N [--train]).
 
 
 def test_training_step_rolls_back_a_rejected_fp16_attempt():
@@ -743,3 +735,46 @@ def test_training_step_rolls_back_a_rejected_fp16_attempt():
         if p.grad is not None:
             assert torch.equal(p.grad, g_retry[n]), n
     md["flow"].eval(); md["input_embedder"].eval()
+
+
+def _flat_adam_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flowcompare_amd import shard
+        torch.manual_seed(5)
+        shapes = [(300, 512), (512,), (7,), (4097,), (64, 3, 1, 1), (1, 300)]
+        ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        reducer = shard.GradientReducer(ps, bucket_bytes=256 << 10)              # several buckets
+        opt = shard.FlatAdam(reducer, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+        topt = torch.optim.Adam(ref, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+        worst_n = 0.0
+        for it in range(4):
+            reducer.zero_grad()
+            gs = [torch.randn(s, device=DEV) * (10.0 if it == 1 else 0.1) for s in shapes]
+            for p, r, g in zip(ps, ref, gs):
+                p.grad.copy_(g)
+                r.grad = g.clone()
+            tn = torch.nn.utils.clip_grad_norm_(ref, max_norm=1.0)
+            topt.step()
+            n = opt.step(max_norm=1.0)
+            worst_n = max(worst_n, abs(float(n) - float(tn)) / float(tn))
+        err = max(float((p.detach() - r.detach()).abs().max()) for p, r in zip(ps, ref))
+        sd = opt.state_dict()
+        tsd = topt.state_dict()
+        merr = max(float((sd["state"][j]["exp_avg"] - tsd["state"][j]["exp_avg"]).abs().max()) for j in range(len(ps)))
+        q.put((rank, err, worst_n, merr))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_adam_matches_torch_adam_with_clipping():
+    """The native optimiser step (global-norm clip + Adam on the reducer's flat buffers, csrc/train_optim.hip) against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.Adam over four steps, one of them clipped hard; moments exported in torch's layout."""
+    res, codes = _spawn(_flat_adam_worker, 1)
+    assert codes == [0]
+    _, err, worst_n, merr = res[0]
+    print(f"FlatAdam vs torch Adam after 4 steps: max |dp| {err:.2e}, gradient norm rel. error {worst_n:.1e}, exp_avg max diff {merr:.1e}")
+    assert err < 2e-6 and worst_n < 1e-6 and merr < 1e-7
