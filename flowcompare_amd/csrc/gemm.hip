@@ -20,6 +20,7 @@
 #include "activations.h"
 #include "spline.h"
 #include <atomic>
+#include <type_traits>
 #include <cstdio>
 
 namespace fc {
@@ -559,34 +560,58 @@ void gemm_f32_kernel(const GemmParams p) {
     // ------------------------------------------------------------------ epilogues
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15
     if constexpr (EPI == EPI_LINEAR) {
+        if (VAR == 8 && e.inverse == 2) return;                      // (diagnostic knob 14 = 2: main loop only, results invalid)
+        // The activation and the output format are wave-uniform run-time values: they are dispatched ONCE, outside the element loops
+        // (a `switch (act)` per element compiled to ~12 branches per output value -- incl. the ELU path's expm1f -- and cost the
+        // 256x128 tile 18 us per tile, 40 % of a 512 -> 512 layer; round 2).  Each body below is straight-line code over the tile.
         float omax = 0.f;
+        auto body = [&](auto act_tag, auto fmt_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            constexpr int FMT = decltype(fmt_tag)::value;             // 1: fp32 C, 2: limb image C16, 3: both
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            if (j < nvalid) {
-                const int col = wave_n0 + j * 32 + li;
+            for (int j = 0; j < TN; ++j) {
+                if (j < nvalid) {
+                    const int col = wave_n0 + j * 32 + li;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
+                    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const float v = act_apply(acc[i][j][r], e.act);
-                        if (e.C) e.C[(size_t)row * e.ldc + col] = v;
-                        if (e.C16) {
-                            // the output ALSO / ONLY as the fp16 limb image a following split-fp16 GEMM copies (its 30 column tiles
-                            // would each re-split the same rows): lanes (c, c+1) pair their halves, one 32-bit store per lane
-                            omax = fmaxf(omax, fabsf(v));
-                            const _Float16 hb = (_Float16)v;
-                            const _Float16 lb = (_Float16)((v - (float)hb) * 2048.0f);
-                            const unsigned hu = __builtin_bit_cast(unsigned short, hb), lu = __builtin_bit_cast(unsigned short, lb);
-                            const unsigned mine = (li & 1) ? lu : hu, give = (li & 1) ? hu : lu;
-                            const unsigned got = __shfl_xor(give, 1, 64);
-                            const unsigned word = (li & 1) ? (got | (mine << 16)) : (mine | (got << 16));
-                            const int c0 = col & ~1;
-                            *reinterpret_cast<unsigned*>(e.C16 + ((size_t)row * (p.N_pad >> 4) + (c0 >> 4)) * 32 + ((li & 1) ? 16 : 0) + (c0 & 15)) = word;
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            float v = acc[i][j][r];
+                            if constexpr (ACT == FC_ACT_GELU) v = fc_gelu(v);
+                            else if constexpr (ACT == FC_ACT_RELU) v = v > 0.f ? v : 0.f;
+                            else if constexpr (ACT == FC_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+                            else if constexpr (ACT == FC_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
+                            if constexpr (FMT & 1) e.C[(size_t)row * e.ldc + col] = v;
+                            if constexpr (FMT & 2) {
+                                // the output ALSO / ONLY as the fp16 limb image a following split-fp16 GEMM copies (its 30 column tiles
+                                // would each re-split the same rows): lanes (c, c+1) pair their halves, one 32-bit store per lane
+                                omax = fmaxf(omax, fabsf(v));
+                                const _Float16 hb = (_Float16)v;
+                                const _Float16 lb = (_Float16)((v - (float)hb) * 2048.0f);
+                                const unsigned hu = __builtin_bit_cast(unsigned short, hb), lu = __builtin_bit_cast(unsigned short, lb);
+                                const unsigned mine = (li & 1) ? lu : hu, give = (li & 1) ? hu : lu;
+                                const unsigned got = __shfl_xor(give, 1, 64);
+                                const unsigned word = (li & 1) ? (got | (mine << 16)) : (mine | (got << 16));
+                                const int c0 = col & ~1;
+                                *reinterpret_cast<unsigned*>(e.C16 + ((size_t)row * (p.N_pad >> 4) + (c0 >> 4)) * 32 + ((li & 1) ? 16 : 0) + (c0 & 15)) = word;
+                            }
                         }
                     }
                 }
             }
+        };
+        auto by_fmt = [&](auto act_tag) {
+            if (e.C && e.C16) body(act_tag, std::integral_constant<int, 3>{});
+            else if (e.C16) body(act_tag, std::integral_constant<int, 2>{});
+            else body(act_tag, std::integral_constant<int, 1>{});
+        };
+        switch (e.act) {
+            case FC_ACT_GELU: by_fmt(std::integral_constant<int, FC_ACT_GELU>{}); break;
+            case FC_ACT_RELU: by_fmt(std::integral_constant<int, FC_ACT_RELU>{}); break;
+            case FC_ACT_ELU: by_fmt(std::integral_constant<int, FC_ACT_ELU>{}); break;
+            case FC_ACT_LRELU02: by_fmt(std::integral_constant<int, FC_ACT_LRELU02>{}); break;
+            default: by_fmt(std::integral_constant<int, FC_ACT_NONE>{}); break;
         }
         if (omax >= 65504.0f) atomicOr(p.ovf, 1);                 // (omax stays 0 without a limb-image output)
     } else if constexpr (EPI == EPI_LNQ) {
@@ -799,6 +824,7 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         if (e.C16 && !(f16 && g_gemm_bigtile == 3 && L.N_pad > 64 && L.N_pad % 16 == 0))
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: limb-image output exists on the eight-wave split-fp16 tile only");
         if (e.A16) {
+            p.e.inverse = g_spline_ablate;
             // A arrives as the limb image of the producing layer (limb-chained MLP): the copy-only main loops
             if (!(f16 && g_gemm_bigtile == 3 && L.nseg == 1 && L.N_pad > 64 && L.n_alloc >= round_up(L.N_pad, 128)))
                 throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: a limb-image A operand needs the split-fp16 loop, one segment and N > 64");
