@@ -102,6 +102,21 @@ void gemm_f32_kernel(const GemmParams p) {
     //      global loads overlap the first tile's loads instead of forming a dependent tail after the last MFMA.
     //      Every runtime condition is hoisted OUTSIDE the unrolled element loops (a per-element "load or not" makes
     //      hipcc branch and wait vmcnt(0) around each load).
+    // fused spline epilogue: the x2 values (and the log-det slot) this thread will update after the main loop are fetched NOW -- their
+    // HBM latency then hides under the k loop instead of standing exposed between the tile's last MFMA and its spline evaluation
+    constexpr int SPL_PER_THREAD = EPI == EPI_SPLINE ? (BM * 5 + NT - 1) / NT : 1;      // (K = 8: 5 dims per 128-column tile; K = 4 / 16 re-load below)
+    float spl_x[SPL_PER_THREAD];
+    float spl_ldj = 0.f;
+    if constexpr (EPI == EPI_SPLINE) {
+        const int per = 3 * e.spline_K + 1, DPT = BN / per, dim0 = bn * DPT;
+#pragma unroll
+        for (int k = 0; k < SPL_PER_THREAD; ++k) {
+            const int it = tid + k * NT, row = it % BM, dl = it / BM;
+            spl_x[k] = (DPT == 5 && it < BM * DPT && dim0 + dl < e.d2 && m0 + row < e.rows_valid)
+                           ? e.xbuf[(size_t)(m0 + row) * e.ldx + e.x2_col0 + dim0 + dl] : 0.f;
+        }
+        if (tid < BM) spl_ldj = e.ldj_part[(size_t)bn * e.ldj_pitch + m0 + tid];
+    }
     floatx16 acc[TM][TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -652,23 +667,39 @@ void gemm_f32_kernel(const GemmParams p) {
         __syncthreads();
         const int K = e.spline_K, per = 3 * K + 1, DPT = BN / per;
         const int dim0 = bn * DPT;
-        for (int it = tid; it < BM * DPT; it += NT) {
-            const int row = it % BM, dl = it / BM;
-            float lad = 0.f;
-            if (dim0 + dl < e.d2 && m0 + row < e.rows_valid) {
-                float* xp = e.xbuf + (size_t)(m0 + row) * e.ldx + e.x2_col0 + dim0 + dl;
-                float y;
-                if (e.inverse == 1) { y = *xp + tile[row * TP + dl * per]; lad = tile[row * TP + dl * per + 1]; }   // (diagnostic knob 14: no spline evaluation)
-                else rq_any(K, *xp, tile + row * TP + dl * per, 1, false, y, lad);
-                *xp = y;
+        if (DPT == 5) {
+#pragma unroll
+            for (int k = 0; k < SPL_PER_THREAD; ++k) {                  // K = 8: x2 arrives from the prefetch at the top of the kernel
+                const int it = tid + k * NT, row = it % BM, dl = it / BM;
+                if (it < BM * DPT) {
+                    float lad = 0.f;
+                    if (dim0 + dl < e.d2 && m0 + row < e.rows_valid) {
+                        float y;
+                        if (e.inverse == 1) { y = spl_x[k] + tile[row * TP + dl * per]; lad = tile[row * TP + dl * per + 1]; }   // (diagnostic knob 14: no spline evaluation)
+                        else rq_any(K, spl_x[k], tile + row * TP + dl * per, 1, false, y, lad);
+                        e.xbuf[(size_t)(m0 + row) * e.ldx + e.x2_col0 + dim0 + dl] = y;
+                    }
+                    part[dl * BM + row] = lad;
+                }
             }
-            part[dl * BM + row] = lad;
+        } else {
+            for (int it = tid; it < BM * DPT; it += NT) {
+                const int row = it % BM, dl = it / BM;
+                float lad = 0.f;
+                if (dim0 + dl < e.d2 && m0 + row < e.rows_valid) {
+                    float* xp = e.xbuf + (size_t)(m0 + row) * e.ldx + e.x2_col0 + dim0 + dl;
+                    float y;
+                    rq_any(K, *xp, tile + row * TP + dl * per, 1, false, y, lad);
+                    *xp = y;
+                }
+                part[dl * BM + row] = lad;
+            }
         }
         __syncthreads();
         if (tid < BM) {
             float sum = 0.f;
             for (int dl = 0; dl < DPT; ++dl) sum += part[dl * BM + tid];
-            e.ldj_part[(size_t)bn * e.ldj_pitch + m0 + tid] += sum;      // this (tile, row) slot has one owner per launch: reproducible
+            e.ldj_part[(size_t)bn * e.ldj_pitch + m0 + tid] = spl_ldj + sum;      // this (tile, row) slot has one owner per launch: reproducible
         }
     } else {
         static_assert(EPI == EPI_LINEAR || (TN % 2 == 0), "pair-packed epilogues need an even number of column tiles");
