@@ -53,7 +53,7 @@ struct GemmParams {
 constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
-__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN > 128 ? 1 : (BM == 128 && WM * WN == 8 && VAR != 8) ? 4 : 2)))   // resident waves per SIMD the register budget must allow
+__global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN > 128 ? 1 : (BM == 128 && WM * WN == 8) ? 4 : 2)))   // resident waves per SIMD the register budget must allow
 void gemm_f32_kernel(const GemmParams p) {
     constexpr int NT = WM * WN * 64;                       // 4 or 8 waves per workgroup
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -186,7 +186,7 @@ void gemm_f32_kernel(const GemmParams p) {
         }
     }
 
-    if constexpr (VAR == 8) {
+    if constexpr (VAR == 8 || VAR == 9) {
         // ================= split-fp16 main loop on LDS-DMA: BOTH operands arrive as fp16 limb images =================
         // A is the image its producer's epilogue wrote (e.A16, [rows][K/16][hi 16 | lo' 16]), W the host-packed one (p.W2): the main
         // loop converts nothing, so global -> LDS is a byte copy and goes through `global_load_lds_dwordx4` (no staging VGPRs, no
@@ -198,8 +198,13 @@ void gemm_f32_kernel(const GemmParams p) {
         //   chunk c ^ ((r >> 1) & 7): with 128-byte rows two rows share a 256-byte bank row, and ds_read_b128's 16-lane groups
         //   ({0-3,12-15,20-27}, ...) then hit 16 distinct 16-byte slots.  The DMA writes LDS linearly (wave base + lane * 16), so the
         //   permutation is applied to the per-lane SOURCE address and again on the read (same involution on both sides).
-        static_assert(BM == 256 && BN == 128 && WM == 4 && WN == 2, "LDS-DMA loop: written for the 256x128 tile on 4x2 waves");
-        constexpr int ROWB8 = 128, STAGE8 = (BM + BN) * ROWB8;        // three stages (launch_cfg reserves 3 * STAGE8)
+        // VAR 9: the same loop on a 128 x 128 tile with FOUR waves of 64 x 64 and TWO LDS stages of 32 KB, so that two workgroups fit a
+        // CU (2 x 64 KB of stages / 2 x 69 KB with the spline epilogue's parameter tile; 2 waves per SIMD): one workgroup's epilogue
+        // then overlaps the other's main loop, which the one-workgroup-per-CU 256-row tile cannot do.
+        static_assert(BN == 128 && WN == 2 && ((VAR == 8 && BM == 256 && WM == 4) || (VAR == 9 && BM == 128 && WM == 2)),
+                      "LDS-DMA loop: 256x128 on 4x2 waves (VAR 8) or 128x128 on 2x2 waves (VAR 9)");
+        constexpr int NST8 = VAR == 8 ? 3 : 2;
+        constexpr int ROWB8 = 128, STAGE8 = (BM + BN) * ROWB8;        // launch_cfg reserves NST8 * STAGE8
         constexpr int PPW = STAGE8 / 1024 / (NT / 64);                       // 1-KB DMA pieces per wave and stage: 6
         typedef __attribute__((address_space(3))) char lds_char;
         typedef const __attribute__((address_space(1))) char glb_char;
@@ -232,39 +237,51 @@ void gemm_f32_kernel(const GemmParams p) {
                 for (int r = 0; r < 16; ++r) corr[i][j][r] = 0.f;
         const int xsw = (li >> 1) & 7;                                      // (row >> 1) & 7 of every row this lane reads (tiles are 32-row aligned)
         const int a_row = (wr * TM * 32 + li) * ROWB8, b_row = (BM + wc * TN * 32 + li) * ROWB8;
-        FC_DMA8(0, 0)
-        FC_DMA8((1 < KT ? 1 : KT - 1), 1)
-        int st = 0;
-        for (int kt = 0; kt < KT; ++kt) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");      // this wave's pieces of tile kt have landed (tile kt+1 may fly on)
-            __builtin_amdgcn_s_barrier();                                   // ... and everybody's; everybody is done reading tile kt-1
-            const int kn = kt + 2 < KT ? kt + 2 : KT - 1;                   // (tail: harmless re-loads into a stage nobody reads again)
-            const int sn = st >= 1 ? st - 1 : 2;                            // (kt + 2) % 3
-            FC_DMA8(kn, sn)
-            const char* sA = smc + st * STAGE8 + a_row;
-            const char* sB = smc + st * STAGE8 + b_row;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                f16x8 af8[TM][2], bf8[TN][2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int off = ((sub * 4 + q * 2 + lh) ^ xsw) * 16;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) af8[i][q] = *reinterpret_cast<const f16x8*>(sA + i * 32 * ROWB8 + off);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bf8[j][q] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB8 + off);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][0], bf8[j][0], acc[i][j], 0, 0, 0);     /* hi * hi */
-                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][0], bf8[j][1], corr[i][j], 0, 0, 0);   /* hi * lo' */
-                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][1], bf8[j][0], corr[i][j], 0, 0, 0);   /* lo' * hi */
-                    }
-            }
-            st = st == 2 ? 0 : st + 1;
+#define FC_MMA8_STAGE(ST_)                                                                                         \
+        {                                                                                                          \
+            const char* sA = smc + (ST_) * STAGE8 + a_row;                                                         \
+            const char* sB = smc + (ST_) * STAGE8 + b_row;                                                         \
+            _Pragma("unroll") for (int sub = 0; sub < 2; ++sub) {                                                  \
+                f16x8 af8[TM][2], bf8[TN][2];                                                                      \
+                _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                    \
+                    const int off = ((sub * 4 + q * 2 + lh) ^ xsw) * 16;                                           \
+                    _Pragma("unroll") for (int i = 0; i < TM; ++i) af8[i][q] = *reinterpret_cast<const f16x8*>(sA + i * 32 * ROWB8 + off); \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j) bf8[j][q] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB8 + off); \
+                }                                                                                                  \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
+                    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][0], bf8[j][0], acc[i][j], 0, 0, 0);     /* hi * hi */  \
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][0], bf8[j][1], corr[i][j], 0, 0, 0);   /* hi * lo' */ \
+                        corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][1], bf8[j][0], corr[i][j], 0, 0, 0);   /* lo' * hi */ \
+                    }                                                                                              \
+            }                                                                                                      \
         }
+        if constexpr (NST8 == 3) {
+            FC_DMA8(0, 0)
+            FC_DMA8((1 < KT ? 1 : KT - 1), 1)
+            int st = 0;
+            for (int kt = 0; kt < KT; ++kt) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");      // this wave's pieces of tile kt have landed (tile kt+1 may fly on)
+                __builtin_amdgcn_s_barrier();                                   // ... and everybody's; everybody is done reading tile kt-1
+                const int kn = kt + 2 < KT ? kt + 2 : KT - 1;                   // (tail: harmless re-loads into a stage nobody reads again)
+                const int sn = st >= 1 ? st - 1 : 2;                            // (kt + 2) % 3
+                FC_DMA8(kn, sn)
+                FC_MMA8_STAGE(st)
+                st = st == 2 ? 0 : st + 1;
+            }
+        } else {
+            // two stages: tile kt+1 is in flight while tile kt is multiplied (issued right behind the barrier that frees its stage)
+            FC_DMA8(0, 0)
+            int st = 0;
+            for (int kt = 0; kt < KT; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 1 < KT) FC_DMA8(kt + 1, (st ^ 1))
+                FC_MMA8_STAGE(st)
+                st ^= 1;
+            }
+        }
+#undef FC_MMA8_STAGE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the tail's re-loads: nothing may land in LDS once the epilogue owns it
         __syncthreads();
 #pragma unroll
@@ -575,41 +592,47 @@ void gemm_f32_kernel(const GemmParams p) {
     // ------------------------------------------------------------------ epilogues
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15
     if constexpr (EPI == EPI_LINEAR) {
-        if (VAR == 8 && e.inverse == 2) return;                      // (diagnostic knob 14 = 2: main loop only, results invalid)
+        if ((VAR == 8 || VAR == 9) && e.inverse == 2) return;        // (diagnostic knob 14 = 2: main loop only, results invalid)
         // The activation and the output format are wave-uniform run-time values: they are dispatched ONCE, outside the element loops
         // (a `switch (act)` per element compiled to ~12 branches per output value -- incl. the ELU path's expm1f -- and cost the
         // 256x128 tile 18 us per tile, 40 % of a 512 -> 512 layer; round 2).  Each body below is straight-line code over the tile.
         float omax = 0.f;
+        // 64-bit bases once per wave, 32-bit offsets inside the tile (a size_t product per element cost two 64-bit multiply-adds each)
+        float* const cbase = e.C ? e.C + (size_t)wave_m0 * e.ldc + wave_n0 : nullptr;
+        const int rp16 = (p.N_pad >> 4) * 32;                          // ushorts per row of the limb image
+        unsigned short* const hbase = e.C16 ? e.C16 + (size_t)wave_m0 * rp16 + (size_t)(wave_n0 >> 4) * 32 : nullptr;
         auto body = [&](auto act_tag, auto fmt_tag) {
             constexpr int ACT = decltype(act_tag)::value;
             constexpr int FMT = decltype(fmt_tag)::value;             // 1: fp32 C, 2: limb image C16, 3: both
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (j < nvalid) {
-                    const int col = wave_n0 + j * 32 + li;
+                    const int cl = j * 32 + li;                       // column inside the wave's strip
+                    const int c0 = cl & ~1;
+                    const int hoff = (c0 >> 4) * 32 + ((li & 1) ? 16 : 0) + (c0 & 15);
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int row = wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // row inside the wave's strip
                             float v = acc[i][j][r];
                             if constexpr (ACT == FC_ACT_GELU) v = fc_gelu(v);
                             else if constexpr (ACT == FC_ACT_RELU) v = v > 0.f ? v : 0.f;
                             else if constexpr (ACT == FC_ACT_ELU) v = v > 0.f ? v : expm1f(v);
                             else if constexpr (ACT == FC_ACT_LRELU02) v = v > 0.f ? v : 0.2f * v;
-                            if constexpr (FMT & 1) e.C[(size_t)row * e.ldc + col] = v;
+                            if constexpr (FMT & 1) cbase[rl * e.ldc + cl] = v;
                             if constexpr (FMT & 2) {
                                 // the output ALSO / ONLY as the fp16 limb image a following split-fp16 GEMM copies (its 30 column tiles
-                                // would each re-split the same rows): lanes (c, c+1) pair their halves, one 32-bit store per lane
+                                // would each re-split the same rows): lanes (c, c+1) swap one half through a DPP quad permute
+                                // ([1,0,3,2]: a VALU move, not the LDS round trip __shfl_xor compiles to) and store one 32-bit word each
                                 omax = fmaxf(omax, fabsf(v));
                                 const _Float16 hb = (_Float16)v;
                                 const _Float16 lb = (_Float16)((v - (float)hb) * 2048.0f);
                                 const unsigned hu = __builtin_bit_cast(unsigned short, hb), lu = __builtin_bit_cast(unsigned short, lb);
                                 const unsigned mine = (li & 1) ? lu : hu, give = (li & 1) ? hu : lu;
-                                const unsigned got = __shfl_xor(give, 1, 64);
+                                const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xF, 0xF, true);
                                 const unsigned word = (li & 1) ? (got | (mine << 16)) : (mine | (got << 16));
-                                const int c0 = col & ~1;
-                                *reinterpret_cast<unsigned*>(e.C16 + ((size_t)row * (p.N_pad >> 4) + (c0 >> 4)) * 32 + ((li & 1) ? 16 : 0) + (c0 & 15)) = word;
+                                *reinterpret_cast<unsigned*>(hbase + rl * rp16 + hoff) = word;
                             }
                         }
                     }
@@ -657,6 +680,7 @@ void gemm_f32_kernel(const GemmParams p) {
         if (e.inverse == 2) return;                                  // (diagnostic knob 14: main loop only)
         float* tile = smem;                                          // aliases the staging buffers (all reads are behind the loop's last barrier)
         float* part = smem + BM * TP;                                // [DPT][BM] log-det terms
+        if (e.inverse != 3) {                                        // (diagnostic knob 14 = 3: no parameter-tile write)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -664,7 +688,9 @@ void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     tile[(wr * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TP + wc * TN * 32 + j * 32 + li] = acc[i][j][r];
+        } else { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15])); }
         __syncthreads();
+        if (e.inverse == 5) return;                                  // (diagnostic knob 14 = 5: main loop + parameter-tile write + barrier)
         const int K = e.spline_K, per = 3 * K + 1, DPT = BN / per;
         const int dim0 = bn * DPT;
         if (DPT == 5) {
@@ -676,8 +702,9 @@ void gemm_f32_kernel(const GemmParams p) {
                     if (dim0 + dl < e.d2 && m0 + row < e.rows_valid) {
                         float y;
                         if (e.inverse == 1) { y = spl_x[k] + tile[row * TP + dl * per]; lad = tile[row * TP + dl * per + 1]; }   // (diagnostic knob 14: no spline evaluation)
-                        else rq_any(K, spl_x[k], tile + row * TP + dl * per, 1, false, y, lad);
-                        e.xbuf[(size_t)(m0 + row) * e.ldx + e.x2_col0 + dim0 + dl] = y;
+                        else rq_spline_fwd<8>(spl_x[k], tile + row * TP + dl * per, 1, y, lad);        // DPT == 5 <=> K == 8
+                        if (e.inverse != 4) e.xbuf[(size_t)(m0 + row) * e.ldx + e.x2_col0 + dim0 + dl] = y;      // (diagnostic knob 14 = 4: no x2 store)
+                        else asm volatile("" :: "v"(y));
                     }
                     part[dl * BM + row] = lad;
                 }
@@ -774,7 +801,14 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_lnq_fold = 1, g_fused_spline = 1, g_gemm_dma = 0, g_spline_ablate = 0, g_gemm_dma_linear = 1, g_limb_chain_all = 0, g_gemm_prefetch3 = 0;   // g_gemm_prefetch3 (knob 17): VAR 6, bit-identical, measured 3.5 % slower on the Linear family   // g_limb_chain_all (knob 16): every hidden activation of the coupling MLP as a limb image -- correct, 2 % slower end to end   // g_gemm_dma (knob 13): the LDS-DMA loop (VAR 8) for the fused spline GEMM -- bit-identical results, measured 2.6 % slower than VAR 7     // tuning knobs (fc_debug_set), defaults = shipped configuration
+// tuning knobs (fc_debug_set), defaults = shipped configuration.  Every alternative below is kept because a test pins it against the
+// shipped path (tests/test_gpu_flow.py::test_every_kernel_variant_agrees...) and DESIGN.md section 6 quotes its measurement.
+int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_lnq_fold = 1, g_fused_spline = 1;
+int g_gemm_dma = 2;          // knob 13: fused spline GEMM: 2 = LDS-DMA loop on the 128x128 four-wave tile (VAR 9, shipped), 1 = on the 256x128 tile (VAR 8), 0 = register-staged (VAR 7); bit-identical results
+int g_spline_ablate = 0;     // knob 14: diagnostics, results invalid (1 = no spline evaluation, 2 = main loop only, 3 = no parameter-tile write, 4 = no x2 store, 5 = stop behind the tile write)
+int g_gemm_dma_linear = 2;   // knob 15: limb-image A in a Linear layer: 2 = LDS-DMA loop on the 128x128 four-wave tile (shipped), 1 = on the 256x128 tile, 0 = register-staged
+int g_limb_chain_all = 1;    // knob 16: every hidden activation of the coupling MLP exists only as a limb image (A16 / residual16 / C16)
+int g_gemm_prefetch3 = 0;    // knob 17: three register sets of prefetch in the Linear loop (VAR 6): bit-identical, measured 3.5 % slower
 
 static thread_local int* t_fp16_flag = nullptr;
 static std::atomic<long> g_fp16_fallbacks{0};
@@ -805,7 +839,7 @@ bool Fp16Guard::overflowed() {
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 6 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : VAR == 9 ? 2 * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 6 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
     constexpr size_t lds_epi = EPI == EPI_SPLINE ? ((size_t)BM * (BN + 1) + (size_t)BM * 9) * sizeof(float) : 0;   // tile + <= 9 dims of log-dets
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
@@ -859,7 +893,8 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             // A arrives as the limb image of the producing layer (limb-chained MLP): the copy-only main loops
             if (!(f16 && g_gemm_bigtile == 3 && L.nseg == 1 && L.N_pad > 64 && L.n_alloc >= round_up(L.N_pad, 128)))
                 throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: a limb-image A operand needs the split-fp16 loop, one segment and N > 64");
-            if (g_gemm_dma_linear && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 8>(p, s); }
+            if (g_gemm_dma_linear == 2) { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 2, 2, EPI_LINEAR, 9>(p, s); }
+            else if (g_gemm_dma_linear && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 8>(p, s); }
             else { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 4, 2, EPI_LINEAR, 7>(p, s); }
         } else if (L.N_pad <= 64) {
             p.nbm = rows_alloc / 128;
@@ -904,7 +939,8 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         p.nbm = rows_alloc / 128;
         if (f16 && e.A16 && g_gemm_bigtile == 3) {
             if (L.nseg != 1) throw Error(FC_ERR_INVALID, "launch_gemm: a limb-image A operand must be the only segment");
-            if (g_gemm_dma && rows_alloc % 256 == 0 && L.n_alloc >= round_up(L.N_pad, 128)) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_SPLINE, 8>(p, s); }
+            if (g_gemm_dma == 2 && L.n_alloc >= round_up(L.N_pad, 128)) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 9>(p, s);
+            else if (g_gemm_dma == 1 && rows_alloc % 256 == 0 && L.n_alloc >= round_up(L.N_pad, 128)) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_SPLINE, 8>(p, s); }
             else launch_cfg<128, 128, 4, 2, EPI_SPLINE, 7>(p, s);
         }
         else if (f16 && g_gemm_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_SPLINE, 5>(p, s);

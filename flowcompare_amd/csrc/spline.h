@@ -96,6 +96,68 @@ __device__ __forceinline__ void rq_spline_elem(float x, const float* u, int us, 
     }
 }
 
+// Forward direction only, BRANCH-FREE (the fused GEMM epilogue evaluates 2-3 independent elements per thread as straight-line code, so
+// the compiler can interleave their dependency chains; the general routine above compiles to ~14 divergent branches per element for
+// its bin selection).  Same algorithm and quirks; differences are rounding-level only: exp via one fma + v_exp (log2 e folded into the
+// argument), the softmax scale folded into the prefix sums, bin edges picked by running selects instead of knot arrays, the two
+// derivative logits by an indexed read.  u must be readable at every index 0 .. 3K (it is: the LDS parameter tile).
+template <int K>
+__device__ __forceinline__ void rq_spline_fwd(float x, const float* u, int us, float& y, float& lad) {
+    constexpr float B = 3.0f, MINW = 1e-3f, MINH = 1e-3f, MIND = 1e-3f, L2E = 1.4426950408889634f;
+    const bool inside = x >= -B && x <= B;
+    float ew[K], eh[K], mw = u[0], mh = u[K * us];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { ew[i] = u[i * us]; eh[i] = u[(K + i) * us]; mw = fmaxf(mw, ew[i]); mh = fmaxf(mh, eh[i]); }
+    float sw = 0.f, sh = 0.f;
+    const float ow = -mw * L2E, oh = -mh * L2E;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        ew[i] = __builtin_amdgcn_exp2f(fmaf(ew[i], L2E, ow)); sw += ew[i];
+        eh[i] = __builtin_amdgcn_exp2f(fmaf(eh[i], L2E, oh)); sh += eh[i];
+    }
+    const float fw = (1.0f - MINW * K) * __builtin_amdgcn_rcpf(sw), fh = (1.0f - MINH * K) * __builtin_amdgcn_rcpf(sh);
+    // widths: bin = #{knots <= x} (last knot + 1e-6), in_cw = largest knot <= x, hi = smallest knot > x
+    float c = 0.f, in_cw = -B, hi = INFINITY;
+    int bin = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        c += fmaf(fw, ew[i], MINW);
+        const float knot = i == K - 1 ? B : fmaf(2.0f * B, c, -B);
+        const bool ge = x >= (i == K - 1 ? knot + 1e-6f : knot);
+        bin += ge ? 1 : 0;
+        in_cw = ge ? knot : in_cw;
+        hi = ge ? hi : fminf(hi, knot);
+    }
+    const float in_w = hi - in_cw;
+    // heights: knot index bin (lower edge) and bin + 1 (upper edge) of the cumulative heights
+    float ch = 0.f, in_ch = -B, ch_hi = B;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        ch += fmaf(fh, eh[i], MINH);
+        const float knot = i == K - 1 ? B : fmaf(2.0f * B, ch, -B);
+        in_ch = (i + 1 == bin) ? knot : in_ch;
+        ch_hi = (i == bin) ? knot : ch_hi;
+    }
+    const float in_h = ch_hi - in_ch;
+    const int b0 = bin > 0 ? bin - 1 : 0;
+    const float ud0 = u[(2 * K + b0) * us], ud1 = u[(2 * K + bin) * us];
+    const float raw0 = bin == 0 ? -1e-3f : ud0;                  // log(exp(1 - min_derivative - 1))
+    const float d0 = MIND + (raw0 > 20.f ? raw0 : fast_log(1.0f + fast_exp(raw0)));
+    const float d1 = MIND + (ud1 > 20.f ? ud1 : fast_log(1.0f + fast_exp(ud1)));
+    const float rw = __builtin_amdgcn_rcpf(in_w);
+    const float delta = in_h * rw;
+    const float th = (x - in_cw) * rw;
+    const float tt = th * (1.0f - th);
+    const float num = in_h * (delta * th * th + d0 * tt);
+    const float den = delta + (d0 + d1 - 2.0f * delta) * tt;
+    const float yy = in_ch + fast_div(num, den);
+    const float omt = 1.0f - th;
+    const float dnum = delta * delta * (d1 * th * th + 2.0f * delta * tt + d0 * omt * omt);
+    const float ll = fast_log(dnum) - 2.0f * fast_log(den);
+    y = inside ? yy : x;
+    lad = inside ? ll : 0.f;
+}
+
 template <int K>
 __device__ __forceinline__ void rq_dispatch(float x, const float* u, int us, bool inv, float& y, float& lad) {
     rq_spline_elem<K>(x, u, us, inv, y, lad);
