@@ -551,7 +551,7 @@ static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t by
     w.cbuf = c.floats(d.nz > 0 ? (size_t)w.P_pad * d.nz_pad : 1);
     w.ldj_slots = ldj_slot_count(f);
     w.ldjp = c.floats(std::max<size_t>((size_t)w.ldj_slots * w.P_pad, 1));
-    w.h16 = (unsigned short*)c.bytes(f.cfg.flow_type == FC_FLOW_SPLINE ? (size_t)w.P_pad * std::max(d.H_pad, 32) * 4 : 16);
+    w.h16 = (unsigned short*)c.bytes(f.cfg.flow_type != FC_FLOW_EXPONENTIAL ? (size_t)w.P_pad * std::max(d.H_pad, 32) * 4 : 16);
     w.lnss = c.floats(f.n_attn > 0 ? (size_t)(std::max(d.A_in, 64) / 64) * w.P_pad : 1);
     w.kv16 = c.bytes(f.n_attn > 0 ? std::max<size_t>(attention_limb_ws_bytes(w.Pc_pad, d.I_pad), 16) : 16);
     if (need) *need = c.off + 256;
@@ -628,13 +628,18 @@ static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, c
     const PackedLinear& last_hidden = b.net.mid.empty() ? b.net.in_layer : b.net.mid.back();
     const bool chain = fused_spline && gemm_limb_chain_ok() && b.net.out_layer.W2 != nullptr && last_hidden.W2 != nullptr &&
                        last_hidden.N_pad == b.net.out_layer.K_pad && last_hidden.N_pad > 64 && b.net.out_layer.nseg == 1;
-    const int cur = run_mlp_hidden(f, b.net, segs, rowscal, w, c.nonlinearity, s, chain ? w.h16 : nullptr);
-    ASeg a{chain ? w.h[0] : w.h[cur], ldh};
+    // the same chain into the affine coupling's (s, t) layer: forward direction, split-fp16 scope, pair-packed epilogue on the DMA tile
+    const bool chain_aff = c.flow_type == FC_FLOW_AFFINE && !inverse && gemm_limb_chain_all_ok() && b.net.out_layer.W2 != nullptr &&
+                           last_hidden.W2 != nullptr && last_hidden.N_pad == b.net.out_layer.K_pad && last_hidden.N_pad % 128 == 0 &&
+                           b.net.out_layer.nseg == 1 && !b.net.mid.empty();
+    const int cur = run_mlp_hidden(f, b.net, segs, rowscal, w, c.nonlinearity, s, (chain || chain_aff) ? w.h16 : nullptr);
+    ASeg a{(chain || chain_aff) ? w.h[0] : w.h[cur], ldh};
     if (c.flow_type == FC_FLOW_AFFINE) {
         GemmEpi e{};
         e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = d.d1_pad; e.d2 = d.d2; e.scale_fn = c.affine_scale_fn;
         e.logprob = logprob; e.rows_valid = w.P; e.inverse = inverse;
         if (!inverse) { e.ldj_part = w.ldjp; e.ldj_pitch = (size_t)w.P_pad; }
+        if (chain_aff) e.A16 = w.h16;
         launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_AFFINE, s);
     } else if (fused_spline) {
         // forward: the parameter GEMM evaluates the splines in its epilogue; only per-tile log-det partials leave the kernel

@@ -952,9 +952,12 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         // forward direction inside a guard scope: 128x128 tile on eight waves with the split-fp16 loop (a wave's 64 columns are one
         // [first 32 | second 32] pair block); log-dets go to the caller's slot buffer.  Otherwise (inverse, bf16-limb fallback
         // pass, fp32 variants): the 128x320 tile whose workgroup owns whole rows.
+        if (e.A16 && !(epi_kind == EPI_AFFINE && f16 && e.ldj_part && !e.inverse && g_gemm_bigtile == 3 && L.nseg == 1 && L.n_alloc >= round_up(L.N_pad, 128)))
+            throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: a limb-image A operand in a pair-packed epilogue exists for the forward affine coupling only");
         if (f16 && e.ldj_part && !e.inverse && g_gemm_bigtile == 3) {
             if (e.ldj_pitch < (size_t)rows_alloc) throw Error(FC_ERR_INVALID, "launch_gemm: log-det slot pitch smaller than the row count");
-            if (epi_kind == EPI_AFFINE) launch_cfg<128, 128, 4, 2, EPI_AFFINE, 5>(p, s);
+            if (e.A16) launch_cfg<128, 128, 2, 2, EPI_AFFINE, 9>(p, s);            // limb-chained MLP: copy-only LDS-DMA loop (a wave's 64 columns = one pair block)
+            else if (epi_kind == EPI_AFFINE) launch_cfg<128, 128, 4, 2, EPI_AFFINE, 5>(p, s);
             else if (epi_kind == EPI_AUGMENT) launch_cfg<128, 128, 4, 2, EPI_AUGMENT, 5>(p, s);
             else launch_cfg<128, 128, 4, 2, EPI_SLICE, 5>(p, s);
         }
