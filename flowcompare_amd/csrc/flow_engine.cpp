@@ -551,13 +551,15 @@ static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t by
     w.cbuf = c.floats(d.nz > 0 ? (size_t)w.P_pad * d.nz_pad : 1);
     w.ldj_slots = ldj_slot_count(f);
     w.ldjp = c.floats(std::max<size_t>((size_t)w.ldj_slots * w.P_pad, 1));
-    w.h16 = (unsigned short*)c.bytes(f.cfg.flow_type != FC_FLOW_EXPONENTIAL ? (size_t)w.P_pad * std::max(d.H_pad, 32) * 4 : 16);
+    w.h16 = (unsigned short*)c.bytes((size_t)w.P_pad * std::max(d.H_pad, 32) * 4);
     w.lnss = c.floats(f.n_attn > 0 ? (size_t)(std::max(d.A_in, 64) / 64) * w.P_pad : 1);
     w.kv16 = c.bytes(f.n_attn > 0 ? std::max<size_t>(attention_limb_ws_bytes(w.Pc_pad, d.I_pad), 16) : 16);
     if (need) *need = c.off + 256;
     return w;
 }
 
+int g_premlp_chain = 0;      // knob 19: limb chain through the pre-attention MLP into the LayerNorm -> q GEMM (K = 256: 8 k-tiles per
+                             // output tile, the tile-boundary cost of the DMA loop outweighs its main loop: measured 1 % slower end to end)
 static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_segs, const float* rowscal, FlowWs& w, int act, hipStream_t s,
                           unsigned short* last_limbs = nullptr) {
     return run_mlp_hidden_generic(m, in_segs, rowscal, act, w.h, std::max(f.d.H_pad, 32), w.P_pad, s, w.P, last_limbs);
@@ -572,12 +574,17 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
         // the whole chain x1 -> MLP -> LayerNorm -> q in one kernel: the 64-row activation tile stays in LDS (premlp.hip)
         launch_premlp(in.ptr, in.lda, pre.in_layer, pre.mid, pre.out_layer, at.q, act, w.q, d.I_pad, w.P_pad, w.P, s);
     } else {
-        const int cur = run_mlp_hidden(f, pre, &in, nullptr, w, act, s);
+        // limb chain through the pre-attention MLP into the LayerNorm -> q GEMM (every hidden activation as a limb image, DMA loops)
+        const PackedLinear& pre_last = pre.mid.empty() ? pre.in_layer : pre.mid.back();
+        const bool chain = g_premlp_chain && at.has_lnq && gemm_lnq_ok() && gemm_limb_chain_all_ok() && w.h16 && !pre.mid.empty() && at.lnq.W2 != nullptr &&
+                           pre_last.W2 != nullptr && pre_last.N_pad == at.lnq.K_pad && pre_last.N_pad % 128 == 0 && at.lnq.nseg == 1;
+        const int cur = run_mlp_hidden(f, pre, &in, nullptr, w, act, s, chain ? w.h16 : nullptr);
         if (at.has_lnq && gemm_lnq_ok()) {
             // out_layer, LayerNorm and the q projection as ONE GEMM (AttnPack::lnq) + a 16 MB finalize pass
             GemmEpi e{};
             e.C = w.q; e.ldc = d.I_pad; e.d2 = d.A_in; e.ldj_part = w.lnss; e.ldj_pitch = (size_t)w.P_pad; e.rows_valid = w.P;
-            ASeg a{w.h[cur], ldh};
+            if (chain) e.A16 = w.h16;
+            ASeg a{chain ? w.h[0] : w.h[cur], ldh};
             launch_gemm(at.lnq, &a, w.P_pad, e, EPI_LNQ, s);
             if (w.kv_limbs) {
                 // the attention kernel applies rstd and the bias while it loads its queries

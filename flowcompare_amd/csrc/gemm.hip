@@ -655,20 +655,24 @@ void gemm_f32_kernel(const GemmParams p) {
     } else if constexpr (EPI == EPI_LNQ) {
         // ---- LayerNorm folded through the layer (common.h): a wave's 64 columns are either hidden columns (sum of squares per row
         //      into the block's slot) or the 64 q columns (stored un-normalised)
-        static_assert(TN == 2 && TM == 1, "LNQ epilogue is written for the eight-wave 128x128 tile");
+        static_assert(TN == 2, "LNQ epilogue: a wave owns one 64-column block (hidden columns or the q columns)");
         if (wave_n0 < e.d2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float t = acc[0][0][r] * acc[0][0][r] + acc[0][1][r] * acc[0][1][r];
-                t = half_wave_sum(t);
-                if (li == 0) e.ldj_part[(size_t)(wave_n0 >> 6) * e.ldj_pitch + wave_m0 + (r & 3) + 8 * (r >> 2) + 4 * lh] = t;
-            }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float t = acc[i][0][r] * acc[i][0][r] + acc[i][1][r] * acc[i][1][r];
+                    t = half_wave_sum(t);
+                    if (li == 0) e.ldj_part[(size_t)(wave_n0 >> 6) * e.ldj_pitch + wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh] = t;
+                }
         } else if (wave_n0 < e.d2 + 64) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    e.C[(size_t)(wave_m0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * e.ldc + (wave_n0 - e.d2) + j * 32 + li] = acc[0][j][r];
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        e.C[(size_t)(wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * e.ldc + (wave_n0 - e.d2) + j * 32 + li] = acc[i][j][r];
         }
     } else if constexpr (EPI == EPI_SPLINE) {
         // ---- fused rational-quadratic spline coupling (forward).  The parameter layer's columns are laid out so that this
@@ -929,7 +933,10 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         if (!e.C || !e.ldj_part || e.d2 % 64 != 0 || L.N_pad != e.d2 + 64 || e.ldc < 64 || e.ldj_pitch < (size_t)rows_alloc || !L.bias)
             throw Error(FC_ERR_INVALID, "launch_gemm: bad LayerNorm -> q fold arguments");
         p.nbm = rows_alloc / 128;
-        launch_cfg<128, 128, 4, 2, EPI_LNQ, 5>(p, s);
+        if (e.A16) {
+            if (L.nseg != 1 || L.n_alloc < round_up(L.N_pad, 128)) throw Error(FC_ERR_INVALID, "launch_gemm: a limb-image A operand must be the only segment");
+            launch_cfg<128, 128, 2, 2, EPI_LNQ, 9>(p, s);
+        } else launch_cfg<128, 128, 4, 2, EPI_LNQ, 5>(p, s);
     } else if (epi_kind == EPI_SPLINE) {
         const int K = e.spline_K;
         p.e.inverse = g_spline_ablate;
