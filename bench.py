@@ -37,7 +37,7 @@ ALG_MFLOP_PER_POINT = {("c1_dgcnn_global_affine", 1024): 396.0, ("c2_dgcnn_attn_
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MATRIX_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparse headline)
 PEAK_HBM_GBS = 8000.0
-SPLIT_MFMA_PER_PRODUCT = {5: 3, 6: 3, 7: 3, 8: 3, 9: 3, 3: 6}   # gemm.hip: the split-fp16 loops (VAR 5; VAR 7 = A operand pre-split) issue 3 fp16 MFMAs per fp32-equivalent product block, the
+SPLIT_MFMA_PER_PRODUCT = {5: 3, 6: 3, 7: 3, 8: 3, 9: 3, 10: 3, 11: 3, 3: 6}   # gemm.hip: the split-fp16 loops (VAR 5; VAR 7 = A operand pre-split) issue 3 fp16 MFMAs per fp32-equivalent product block, the
                                         # split-bf16 loop (VAR 3, its fallback) 6 bf16 MFMAs; both run at the 2500 TFLOP/s dense 16-bit rate
 
 
@@ -271,7 +271,7 @@ def main():
             if var is not None:
                 n = SPLIT_MFMA_PER_PRODUCT[var]
                 achieved, peak = useful * n, PEAK_BF16_MATRIX_TFLOPS
-                note = (f"split-{'fp16' if var in (5, 6, 7, 8, 9) else 'bf16'} loop: achieved = 16-bit MFMA FLOPs actually issued ({n} limb products per "
+                note = (f"split-{'fp16' if var != 3 else 'bf16'} loop: achieved = 16-bit MFMA FLOPs actually issued ({n} limb products per "
                         "fp32-equivalent product, padding excluded) against the dense fp16/bf16 MFMA peak 2500 TFLOP/s; "
                         "useful_fp32_equivalent_tflops is the same launch time priced in fp32-equivalent FLOPs (the fp32-input MFMA "
                         "peak is 157.3 TFLOP/s)")

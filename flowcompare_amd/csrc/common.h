@@ -143,6 +143,7 @@ struct GemmEpi {
     const float* eps = nullptr; int d_in = 0, d1 = 0, d1_pad = 0;   // AUGMENT: latent index = d_in + q ; x1|x2 split
     float clamp = 0.f;         // AUGMENT/SLICE: std clamp (0 = none)
     int inverse = 0;           // AFFINE: x2 = (y2 - t) / (s*g), no log-det ; AUGMENT: sample only (no log-det)
+    int prefetch_dist = 0;     // SPLINE (persistent kernel): != 0 rotates each tile's k loop by a column-tile dependent offset (launch_gemm fills it from knob 21)
     int split = 1 << 30, split_pad = 0;   // AFFINE: transformed dim j lives at column x2_col0 + (j < split ? j : split_pad + j - split)
     const float* post_scale = nullptr;    // AFFINE: optional per-dim factor g folded behind s (CIF: ActNorm of the x part)
     const float* val = nullptr; int ldval = 0;             // SLICE: values whose log N(.; mu, sigma) is ADDED to logprob

@@ -46,11 +46,32 @@ struct GemmParams {
     int N_pad;
     int nbm, nbn;
     int col_group;      // > 0: row-band / column-group tile order for weight matrices that do not fit L2
+    unsigned long long* stamps;   // diagnostic knob 20: 16 x u64 per workgroup (s_memtime at the phase boundaries, HW_ID, wall clock); null otherwise
     GemmEpi e;
 };
 
 
 constexpr int LDS_LD = 36;   // floats per LDS row (32 + 4 pad)
+
+// In-kernel phase stamps of the LDS-DMA kernels (diagnostic knob 20; profiles/micro/spline_gemm_stamps.py): thread 0 of a workgroup stores
+// the shader-clock counter.  Slot 0 entry, 1 prologue issued, 2 first k tile landed, 3 main loop done, 4 epilogue operands ready (LDS tile
+// written / register exchange done), 5 splines evaluated, 6 results stored, 7 HW_ID | XCC_ID << 32, 8 / 9 wall clock (100 MHz) at entry / exit.
+#define FC_STAMP(K_)                                                                                                 \
+    if (p.stamps && threadIdx.x == 0) {                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        p.stamps[(size_t)blockIdx.x * 16 + (K_)] = __builtin_amdgcn_s_memtime();                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+
+// Lanes 0..31 of the result receive lanes 32..63 of v (v_permlane32_swap_b32 swaps the upper half of its first operand with the lower
+// half of its second; lanes 32..63 of the result are unspecified).  Inline assembly: this hipcc's __builtin_amdgcn_permlane32_swap
+// hands back its first result for both elements (profiles/micro/permlane32_swap_probe.hip); the s_nops cover the VALU <-> permlane-swap
+// wait states the compiler cannot schedule around an asm block.
+__device__ __forceinline__ float upper_to_lower(float v) {
+    float a = v, b = 0.f;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return b;
+}
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 __global__ __launch_bounds__(WM * WN * 64) __attribute__((amdgpu_waves_per_eu(BN > 128 ? 1 : (BM == 128 && WM * WN == 8) ? 4 : 2)))   // resident waves per SIMD the register budget must allow
@@ -96,6 +117,13 @@ void gemm_f32_kernel(const GemmParams p) {
     int nvalid = (p.N_pad - wave_n0) / 32;                 // wave-uniform number of live 32-col tiles (for the stores only:
     nvalid = nvalid < 0 ? 0 : (nvalid > TN ? TN : nvalid); // W / bias are allocated zero-padded to the grid, the k-loop is branch free)
     const GemmEpi& e = p.e;
+    if constexpr (VAR == 8 || VAR == 9 || VAR == 10) {
+        if (p.stamps && threadIdx.x == 0) {
+            p.stamps[(size_t)blockIdx.x * 16 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+            p.stamps[(size_t)blockIdx.x * 16 + 8] = wall_clock64();
+        }
+        FC_STAMP(0)
+    }
 
 
     // ---- accumulators start from the epilogue's additive terms (bias, rank-1 extra-context term, residual), so their
@@ -107,7 +135,16 @@ void gemm_f32_kernel(const GemmParams p) {
     constexpr int SPL_PER_THREAD = EPI == EPI_SPLINE ? (BM * 5 + NT - 1) / NT : 1;      // (K = 8: 5 dims per 128-column tile; K = 4 / 16 re-load below)
     float spl_x[SPL_PER_THREAD];
     float spl_ldj = 0.f;
-    if constexpr (EPI == EPI_SPLINE) {
+    if constexpr (EPI == EPI_SPLINE && VAR == 10) {
+        // transposed product (below): this lane evaluates dims 2 lh, 2 lh + 1 (and, lower half, dim 4) of ONE point
+        const int row = m0 + wave * 32 + li, dim0 = bn * 5;
+        const float* xr = e.xbuf + (size_t)row * e.ldx + e.x2_col0 + dim0;
+        const bool rv = row < e.rows_valid;
+        spl_x[0] = rv && dim0 + 2 * lh < e.d2 ? xr[2 * lh] : 0.f;
+        spl_x[1] = rv && dim0 + 2 * lh + 1 < e.d2 ? xr[2 * lh + 1] : 0.f;
+        spl_x[2] = rv && dim0 + 4 < e.d2 ? xr[4] : 0.f;
+        if (lh == 0) spl_ldj = e.ldj_part[(size_t)bn * e.ldj_pitch + row];
+    } else if constexpr (EPI == EPI_SPLINE) {
         const int per = 3 * e.spline_K + 1, DPT = BN / per, dim0 = bn * DPT;
 #pragma unroll
         for (int k = 0; k < SPL_PER_THREAD; ++k) {
@@ -118,6 +155,16 @@ void gemm_f32_kernel(const GemmParams p) {
         if (tid < BM) spl_ldj = e.ldj_part[(size_t)bn * e.ldj_pitch + m0 + tid];
     }
     floatx16 acc[TM][TN];
+    if constexpr (VAR == 10) {
+        // transposed product: the accumulator's ROW index (register r, lane half) walks the tile's columns, so the bias varies per register
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + j * 32 + 8 * g + 4 * lh);      // (the launcher requires a bias)
+                acc[0][j][4 * g + 0] = b4.x; acc[0][j][4 * g + 1] = b4.y; acc[0][j][4 * g + 2] = b4.z; acc[0][j][4 * g + 3] = b4.w;
+            }
+    } else
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         float bv = 0.f;
@@ -186,7 +233,7 @@ void gemm_f32_kernel(const GemmParams p) {
         }
     }
 
-    if constexpr (VAR == 8 || VAR == 9) {
+    if constexpr (VAR == 8 || VAR == 9 || VAR == 10) {
         // ================= split-fp16 main loop on LDS-DMA: BOTH operands arrive as fp16 limb images =================
         // A is the image its producer's epilogue wrote (e.A16, [rows][K/16][hi 16 | lo' 16]), W the host-packed one (p.W2): the main
         // loop converts nothing, so global -> LDS is a byte copy and goes through `global_load_lds_dwordx4` (no staging VGPRs, no
@@ -201,8 +248,14 @@ void gemm_f32_kernel(const GemmParams p) {
         // VAR 9: the same loop on a 128 x 128 tile with FOUR waves of 64 x 64 and TWO LDS stages of 32 KB, so that two workgroups fit a
         // CU (2 x 64 KB of stages / 2 x 69 KB with the spline epilogue's parameter tile; 2 waves per SIMD): one workgroup's epilogue
         // then overlaps the other's main loop, which the one-workgroup-per-CU 256-row tile cannot do.
-        static_assert(BN == 128 && WN == 2 && ((VAR == 8 && BM == 256 && WM == 4) || (VAR == 9 && BM == 128 && WM == 2)),
-                      "LDS-DMA loop: 256x128 on 4x2 waves (VAR 8) or 128x128 on 2x2 waves (VAR 9)");
+        // VAR 10 (fused spline layer): the VAR 9 tile with its four waves stacked along the rows (32 points x 128 columns each) and the
+        // MFMA operands SWAPPED -- weights as the A operand, points as B -- so the accumulator holds, per lane, 64 parameters of ONE
+        // point (the other 64 sit in lane ^ 32).  With the column order of spline.h that is every parameter of 2-3 transformed dims in
+        // registers with compile-time indices: the spline is evaluated straight from the accumulators, the tile never goes through LDS
+        // (no 66 KB parameter tile, no transposition, no epilogue barrier).
+        static_assert(BN == 128 && ((VAR == 8 && BM == 256 && WM == 4 && WN == 2) || (VAR == 9 && BM == 128 && WM == 2 && WN == 2) ||
+                                    (VAR == 10 && BM == 128 && WM == 4 && WN == 1 && EPI == EPI_SPLINE)),
+                      "LDS-DMA loop: 256x128 on 4x2 waves (VAR 8), 128x128 on 2x2 waves (VAR 9) or on 4x1 waves, transposed (VAR 10)");
         constexpr int NST8 = VAR == 8 ? 3 : 2;
         constexpr int ROWB8 = 128, STAGE8 = (BM + BN) * ROWB8;        // launch_cfg reserves NST8 * STAGE8
         constexpr int PPW = STAGE8 / 1024 / (NT / 64);                       // 1-KB DMA pieces per wave and stage: 6
@@ -250,9 +303,15 @@ void gemm_f32_kernel(const GemmParams p) {
                 }                                                                                                  \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
                     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                               \
+                        if constexpr (VAR == 10) {                                                                 \
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf8[j][0], af8[i][0], acc[i][j], 0, 0, 0);   \
+                            corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf8[j][1], af8[i][0], corr[i][j], 0, 0, 0); \
+                            corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf8[j][0], af8[i][1], corr[i][j], 0, 0, 0); \
+                        } else {                                                                                   \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][0], bf8[j][0], acc[i][j], 0, 0, 0);     /* hi * hi */  \
                         corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][0], bf8[j][1], corr[i][j], 0, 0, 0);   /* hi * lo' */ \
                         corr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af8[i][1], bf8[j][0], corr[i][j], 0, 0, 0);   /* lo' * hi */ \
+                        }                                                                                          \
                     }                                                                                              \
             }                                                                                                      \
         }
@@ -272,10 +331,12 @@ void gemm_f32_kernel(const GemmParams p) {
         } else {
             // two stages: tile kt+1 is in flight while tile kt is multiplied (issued right behind the barrier that frees its stage)
             FC_DMA8(0, 0)
+            FC_STAMP(1)
             int st = 0;
             for (int kt = 0; kt < KT; ++kt) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                if (kt == 0) FC_STAMP(2)
                 if (kt + 1 < KT) FC_DMA8(kt + 1, (st ^ 1))
                 FC_MMA8_STAGE(st)
                 st ^= 1;
@@ -283,7 +344,8 @@ void gemm_f32_kernel(const GemmParams p) {
         }
 #undef FC_MMA8_STAGE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the tail's re-loads: nothing may land in LDS once the epilogue owns it
-        __syncthreads();
+        if constexpr (VAR != 10) __syncthreads();                           // (VAR 10's epilogue stays in registers: its waves finish independently)
+        FC_STAMP(3)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -674,6 +736,44 @@ void gemm_f32_kernel(const GemmParams p) {
                     for (int r = 0; r < 16; ++r)
                         e.C[(size_t)(wave_m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * e.ldc + (wave_n0 - e.d2) + j * 32 + li] = acc[i][j][r];
         }
+    } else if constexpr (EPI == EPI_SPLINE && VAR == 10) {
+        // ---- fused rational-quadratic spline coupling evaluated from the accumulator registers (transposed product, K = 8).
+        //      Slot s = 16 j + r of this lane is tile column spline_slot_col(s, lh): slots 0..24 / 25..49 are dims 2 lh / 2 lh + 1,
+        //      slots 50.. of the lower half are parameters 0..13 of dim 4, slots 50..60 of the upper half its parameters 14..24.
+        if (e.inverse == 2) return;                                  // (diagnostic knob 14: main loop only)
+        auto P = [&](int s) -> float { return acc[0][s >> 4][s & 15]; };
+        float t4[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            t4[i] = upper_to_lower(acc[0][3][2 + i]);                 // slot 50 + i
+        }
+        FC_STAMP(4)
+        const int row = m0 + wave * 32 + li, dim0 = bn * 5;
+        const bool rv = row < e.rows_valid;
+        const bool vA = rv && dim0 + 2 * lh < e.d2, vB = rv && dim0 + 2 * lh + 1 < e.d2, vC = rv && lh == 0 && dim0 + 4 < e.d2;
+        float yA, yB, yC, lA, lB, lC;
+        if (e.inverse == 1) {                                        // (diagnostic knob 14 = 1: no spline evaluation)
+            yA = spl_x[0] + P(0); lA = P(1); yB = spl_x[1] + P(25); lB = P(26); yC = spl_x[2] + P(50); lC = P(51);
+        } else {
+            rq_spline_fwd_regs<8>(spl_x[0], [&](int q) { return P(q); }, yA, lA);
+            rq_spline_fwd_regs<8>(spl_x[1], [&](int q) { return P(25 + q); }, yB, lB);
+            rq_spline_fwd_regs<8>(spl_x[2], [&](int q) { return q < 14 ? P(50 + q) : t4[q - 14]; }, yC, lC);
+        }
+        FC_STAMP(5)
+        float* xr = e.xbuf + (size_t)row * e.ldx + e.x2_col0 + dim0;
+        if (vA) xr[2 * lh] = yA;
+        if (vB) xr[2 * lh + 1] = yB;
+        if (vC) xr[4] = yC;
+        lA = vA ? lA : 0.f; lB = vB ? lB : 0.f; lC = vC ? lC : 0.f;
+        // log-dets of dims 2, 3 cross to the lower half; summed in dim order like the LDS-tile epilogues (bit-identical slot values)
+        const float l2 = upper_to_lower(lA), l3 = upper_to_lower(lB);
+        if (lh == 0) {
+            float sum = 0.f;
+            sum += lA; sum += lB; sum += l2; sum += l3; sum += lC;
+            e.ldj_part[(size_t)bn * e.ldj_pitch + row] = spl_ldj + sum;
+        }
+        FC_STAMP(6)
+        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = wall_clock64();
     } else if constexpr (EPI == EPI_SPLINE) {
         // ---- fused rational-quadratic spline coupling (forward).  The parameter layer's columns are laid out so that this
         //      128-column tile holds all 3K+1 parameters of DPT transformed dims (spline.h): the tile goes through LDS (the
@@ -685,15 +785,19 @@ void gemm_f32_kernel(const GemmParams p) {
         float* tile = smem;                                          // aliases the staging buffers (all reads are behind the loop's last barrier)
         float* part = smem + BM * TP;                                // [DPT][BM] log-det terms
         if (e.inverse != 3) {                                        // (diagnostic knob 14 = 3: no parameter-tile write)
+        int tpos[TN];                                                // column -> (dim, parameter) position (K = 8: spline.h's slot order)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) tpos[j] = spline_tile_pos(wc * TN * 32 + j * 32 + li, e.spline_K);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    tile[(wr * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TP + wc * TN * 32 + j * 32 + li] = acc[i][j][r];
+                    tile[(wr * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TP + tpos[j]] = acc[i][j][r];
         } else { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15])); }
         __syncthreads();
+        if constexpr (VAR == 8 || VAR == 9) FC_STAMP(4)
         if (e.inverse == 5) return;                                  // (diagnostic knob 14 = 5: main loop + parameter-tile write + barrier)
         const int K = e.spline_K, per = 3 * K + 1, DPT = BN / per;
         const int dim0 = bn * DPT;
@@ -726,11 +830,16 @@ void gemm_f32_kernel(const GemmParams p) {
                 part[dl * BM + row] = lad;
             }
         }
+        if constexpr (VAR == 8 || VAR == 9) FC_STAMP(5)
         __syncthreads();
         if (tid < BM) {
             float sum = 0.f;
             for (int dl = 0; dl < DPT; ++dl) sum += part[dl * BM + tid];
             e.ldj_part[(size_t)bn * e.ldj_pitch + m0 + tid] = spl_ldj + sum;      // this (tile, row) slot has one owner per launch: reproducible
+        }
+        if constexpr (VAR == 8 || VAR == 9) {
+            FC_STAMP(6)
+            if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = wall_clock64();
         }
     } else {
         static_assert(EPI == EPI_LINEAR || (TN % 2 == 0), "pair-packed epilogues need an even number of column tiles");
@@ -805,10 +914,258 @@ void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
+// ===================================================================================================================================
+// VAR 11: the fused spline layer as a PERSISTENT transposed LDS-DMA GEMM (K = 8 bins).  Same tile, operands, MFMA order and register
+// epilogue as VAR 10 (bit-identical results); what changes is the tile boundary, which the in-kernel stamps (knob 20,
+// profiles/micro/spline_gemm_stamps.py) priced at 6.5 of a workgroup's 25.5 us per tile: 2.6 us from entry until the first k tile has
+// landed, 0.8 us between a workgroup's exit and its successor's entry, 3.1 us of epilogue during which the slot fetches nothing.
+//   * grid = 2 workgroups per CU, each walks tiles t = blockIdx.x, + gridDim.x, ... (the XCD-aware order of the one-tile-per-workgroup
+//     launch: gridDim.x is a multiple of 8, so a workgroup's tiles stay on its XCD's band);
+//   * ONE continuous DMA stream: behind the barrier of a tile's LAST k step the workgroup issues the NEXT tile's first k step into the
+//     free stage (plus its 512 bytes of bias into LDS and its x2 / log-det operands into registers), so that data crosses the
+//     epilogue in flight and the next tile's first barrier finds it landed;
+//   * the epilogue never touches LDS and has no barrier: the four waves evaluate their splines independently, results stay in four
+//     registers and are STORED behind the next tile's first barrier, so no wave waits for a store acknowledgement (stores count in
+//     vmcnt on gfx9) before it may start multiplying again.
+// LDS: 2 stages x 32 KB + 2 x 512 B of bias = 66560 B (two workgroups per CU).
+__device__ __forceinline__ void spline_gemm_persistent(const GemmParams& p, float* smem) {
+    constexpr int BM = 128, BN = 128, ROWB = 128, STAGE = (BM + BN) * ROWB, PPW = 8;
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef const __attribute__((address_space(1))) char glb_char;
+    const GemmEpi& e = p.e;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* smc = reinterpret_cast<char*>(smem);
+    float* biasbuf = smem + 2 * STAGE / 4;                              // [2][128]
+    const int KT = p.KT;
+    const unsigned rowbytes = (unsigned)KT * 128u;
+    const int ntiles = p.nbm * p.nbn, G = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+
+    auto tile_of = [&](int b, int& bm, int& bn) {                       // the XCD-aware order of gemm_f32_kernel
+        const int xcd = b & 7, loc = b >> 3;
+        if (p.col_group > 0) {
+            const int rows_x = p.nbm >> 3, Gc = p.col_group;
+            const int g = loc / (rows_x * Gc);
+            const int rem = loc - g * rows_x * Gc;
+            const int w = p.nbn - g * Gc < Gc ? p.nbn - g * Gc : Gc;
+            const int r = rem / w;
+            bm = xcd * rows_x + r;
+            bn = g * Gc + (rem - r * w);
+        } else {
+            const int q = ntiles >> 3, r = ntiles & 7;
+            const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+            bm = L / p.nbn;
+            bn = L - bm * p.nbn;
+        }
+    };
+    // DMA pieces: piece pc = wave * 8 + i covers stage rows 8 pc .. 8 pc + 7 (rows 0..127: points, 128..255: weight rows); waves 0, 1 fetch
+    // the points, waves 2, 3 the weights, so a wave's source base is scalar and its eight per-lane byte offsets never change
+    unsigned poff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int r = (wave * PPW + i) * 8 + (lane >> 3);
+        const int cl = (lane & 7) ^ ((r >> 1) & 7);
+        poff[i] = (unsigned)(r & (BM - 1)) * rowbytes + cl * 16;
+    }
+    auto src_of = [&](int bm, int bn) -> const char* {
+        return wave < 2 ? reinterpret_cast<const char*>(e.A16) + (size_t)bm * BM * rowbytes : reinterpret_cast<const char*>(p.W2) + (size_t)bn * BN * rowbytes;
+    };
+#define FC_PDMA(SRC_, KT_, ST_)                                                                                       \
+    {                                                                                                                 \
+        const char* src_ = (SRC_) + (size_t)(KT_) * 128;                                                             \
+        _Pragma("unroll") for (int i = 0; i < PPW; ++i)                                                              \
+            __builtin_amdgcn_global_load_lds((glb_char*)(src_ + poff[i]), (lds_char*)(smc + (ST_) * STAGE + (wave * PPW + i) * 1024), 16, 0, 0); \
+    }
+    auto bias_dma = [&](int bn, int par) {                              // 128 floats: waves 0 and 1, 4 bytes per lane
+        if (wave < 2)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) float*)(p.bias + bn * BN + wave * 64 + lane),
+                                             (__attribute__((address_space(3))) float*)(biasbuf + par * 128 + wave * 64), 4, 0, 0);
+    };
+    auto load_x = [&](int bm, int bn, float (&x)[3], float& ldj) {
+        const int row = bm * BM + wave * 32 + li, dim0 = bn * 5;
+        const float* xr = e.xbuf + (size_t)row * e.ldx + e.x2_col0 + dim0;
+        const bool rv = row < e.rows_valid;
+        x[0] = rv && dim0 + 2 * lh < e.d2 ? xr[2 * lh] : 0.f;
+        x[1] = rv && dim0 + 2 * lh + 1 < e.d2 ? xr[2 * lh + 1] : 0.f;
+        x[2] = rv && dim0 + 4 < e.d2 ? xr[4] : 0.f;
+        ldj = lh == 0 ? e.ldj_part[(size_t)bn * e.ldj_pitch + row] : 0.f;
+    };
+#define FC_PSTAMP(K_)                                                                                                 \
+    if (p.stamps && threadIdx.x == 0) {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        p.stamps[(size_t)t * 16 + (K_)] = __builtin_amdgcn_s_memtime();                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
+
+    int bm, bn;
+    tile_of(t, bm, bn);
+    const char* src = src_of(bm, bn);
+    if (p.stamps && threadIdx.x == 0) {
+        p.stamps[(size_t)t * 16 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        p.stamps[(size_t)t * 16 + 8] = wall_clock64();
+    }
+    FC_PSTAMP(0)
+    FC_PDMA(src, (e.prefetch_dist != 0 ? (int)(((unsigned)(bn % 10) * (unsigned)p.KT) / 10u) : 0), 0)
+    bias_dma(bn, 0);
+    float spl_x[3], spl_ldj;
+    load_x(bm, bn, spl_x, spl_ldj);
+    FC_PSTAMP(1)
+
+    floatx16 acc[4], corr[4];
+    const int xsw = (li >> 1) & 7;
+    const int a_row = (wave * 32 + li) * ROWB, b_row = (BM + li) * ROWB;
+    int st = 0, par = 0;
+    // results of the previous tile, stored behind this tile's first barrier
+    bool pend = false;
+    int pbm = 0, pbn = 0;
+    float pyA = 0.f, pyB = 0.f, pyC = 0.f, pldj = 0.f;
+    auto flush = [&]() {
+        const int row = pbm * BM + wave * 32 + li, dim0 = pbn * 5;
+        const bool rv = row < e.rows_valid;
+        float* xr = e.xbuf + (size_t)row * e.ldx + e.x2_col0 + dim0;
+        if (rv && dim0 + 2 * lh < e.d2) xr[2 * lh] = pyA;
+        if (rv && dim0 + 2 * lh + 1 < e.d2) xr[2 * lh + 1] = pyB;
+        if (rv && lh == 0 && dim0 + 4 < e.d2) xr[4] = pyC;
+        if (lh == 0) e.ldj_part[(size_t)pbn * e.ldj_pitch + row] = pldj;
+    };
+
+    // K rotation (knob 21): the ~10 workgroups of an XCD that share a 128-row panel (same row tile, the column tiles of one column group)
+    // run concurrently and, started together, walk its k steps together: every step's first touch of the panel misses L2 for all of
+    // them at once, and a miss holds back the hits queued behind it in the CU's in-order return path (PMC: 92 % L2 hits, yet the texture
+    // data unit waits on the cache a third of the time and a DMA issued a whole k step earlier still kept its wave waiting).  A tile
+    // therefore starts its k loop at step rot(column tile) and wraps around: the sharers are spread over the panel's k range, each k
+    // step is missed by one of them and hit by the others.  fp32 accumulation order changes with it (not bit-identical to VAR 9 / 10).
+    const bool rotate = e.prefetch_dist != 0;
+    auto rot_of = [&](int bn_) -> int { return rotate ? (int)(((unsigned)(bn_ % 10) * (unsigned)KT) / 10u) : 0; };
+    for (;;) {
+        const int tn = t + G;
+        const bool has_next = tn < ntiles;
+        int nbm = 0, nbn = 0;
+        if (has_next) tile_of(tn, nbm, nbn);
+        float nx[3] = {0.f, 0.f, 0.f}, nldj = 0.f;
+        int kidx = rot_of(bn);                                          // k step being multiplied; the DMA runs one ahead
+        for (int kt = 0; kt < KT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of this k step (and anything older) have landed
+            __builtin_amdgcn_s_barrier();                               // ... everybody's have; everybody is done reading the other stage
+            kidx = kidx + 1 < KT ? kidx + 1 : 0;
+            if (kt + 1 < KT) {
+                FC_PDMA(src, kidx, (st ^ 1))
+            } else if (has_next) {                                      // the stream runs on into the next tile
+                src = src_of(nbm, nbn);
+                FC_PDMA(src, rot_of(nbn), (st ^ 1))
+                bias_dma(nbn, par ^ 1);
+                load_x(nbm, nbn, nx, nldj);
+            }
+            if (kt == 0) {
+                FC_PSTAMP(2)
+                if (pend) flush();
+                // accumulators start from the bias (transposed product: it varies along the accumulator's registers)
+                const float* bb = biasbuf + par * 128 + 4 * lh;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bb + j * 32 + 8 * g);
+                        acc[j][4 * g + 0] = b4.x; acc[j][4 * g + 1] = b4.y; acc[j][4 * g + 2] = b4.z; acc[j][4 * g + 3] = b4.w;
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) corr[j][r] = 0.f;
+            }
+            {
+                const char* sA = smc + st * STAGE + a_row;
+                const char* sB = smc + st * STAGE + b_row;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    f16x8 xf[2], wf[4][2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int off = ((sub * 4 + q * 2 + lh) ^ xsw) * 16;
+                        xf[q] = *reinterpret_cast<const f16x8*>(sA + off);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) wf[j][q] = *reinterpret_cast<const f16x8*>(sB + j * 32 * ROWB + off);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][0], xf[0], acc[j], 0, 0, 0);      // hi * hi
+                        corr[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][1], xf[0], corr[j], 0, 0, 0);    // lo' * hi
+                        corr[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][0], xf[1], corr[j], 0, 0, 0);    // hi * lo'
+                    }
+                }
+            }
+            st ^= 1;
+        }
+        FC_PSTAMP(3)
+        // ---- epilogue in registers (see VAR 10 in gemm_f32_kernel): slot s = 16 j + r of this lane is tile column spline_slot_col(s, lh)
+        if (e.inverse != 2) {                                           // (diagnostic knob 14 = 2: main loop only)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] += corr[j][r] * (1.0f / 2048.0f);
+            auto P = [&](int s) -> float { return acc[s >> 4][s & 15]; };
+            float t4[11];
+#pragma unroll
+            for (int i = 0; i < 11; ++i) t4[i] = upper_to_lower(acc[3][2 + i]);      // slots 50..60 of the upper half: dim 4, parameters 14..24
+            FC_PSTAMP(4)
+            const int row = bm * BM + wave * 32 + li, dim0 = bn * 5;
+            const bool rv = row < e.rows_valid;
+            const bool vA = rv && dim0 + 2 * lh < e.d2, vB = rv && dim0 + 2 * lh + 1 < e.d2, vC = rv && lh == 0 && dim0 + 4 < e.d2;
+            float lA, lB, lC;
+            if (e.inverse == 1) {                                       // (diagnostic knob 14 = 1: no spline evaluation)
+                pyA = spl_x[0] + P(0); lA = P(1); pyB = spl_x[1] + P(25); lB = P(26); pyC = spl_x[2] + P(50); lC = P(51);
+            } else {
+                rq_spline_fwd_regs<8>(spl_x[0], [&](int q) { return P(q); }, pyA, lA);
+                rq_spline_fwd_regs<8>(spl_x[1], [&](int q) { return P(25 + q); }, pyB, lB);
+                rq_spline_fwd_regs<8>(spl_x[2], [&](int q) { return q < 14 ? P(50 + q) : t4[q - 14]; }, pyC, lC);
+            }
+            lA = vA ? lA : 0.f; lB = vB ? lB : 0.f; lC = vC ? lC : 0.f;
+            const float l2 = upper_to_lower(lA), l3 = upper_to_lower(lB);
+            float sum = 0.f;
+            sum += lA; sum += lB; sum += l2; sum += l3; sum += lC;      // dim order, like the LDS-tile epilogues (bit-identical slot values)
+            pldj = spl_ldj + sum;
+            pbm = bm; pbn = bn; pend = true;
+            FC_PSTAMP(5)
+        }
+        if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)t * 16 + 9] = wall_clock64();
+        FC_PSTAMP(6)
+        if (!has_next) break;
+        t = tn; bm = nbm; bn = nbn; par ^= 1;
+        spl_x[0] = nx[0]; spl_x[1] = nx[1]; spl_x[2] = nx[2]; spl_ldj = nldj;
+        if (p.stamps && threadIdx.x == 0) {
+            p.stamps[(size_t)t * 16 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+            p.stamps[(size_t)t * 16 + 8] = wall_clock64();
+        }
+        FC_PSTAMP(0)
+        FC_PSTAMP(1)
+    }
+    if (pend) flush();
+#undef FC_PDMA
+#undef FC_PSTAMP
+}
+template <>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void gemm_f32_kernel<128, 128, 4, 1, EPI_SPLINE, 11>(const GemmParams p) {
+    extern __shared__ float smem[];
+    spline_gemm_persistent(p, smem);
+}
+
 // tuning knobs (fc_debug_set), defaults = shipped configuration.  Every alternative below is kept because a test pins it against the
 // shipped path (tests/test_gpu_flow.py::test_every_kernel_variant_agrees...) and DESIGN.md section 6 quotes its measurement.
 int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain = 1, g_lnq_fold = 1, g_fused_spline = 1;
-int g_gemm_dma = 2;          // knob 13: fused spline GEMM: 2 = LDS-DMA loop on the 128x128 four-wave tile (VAR 9, shipped), 1 = on the 256x128 tile (VAR 8), 0 = register-staged (VAR 7); bit-identical results
+int g_gemm_stamp = 0;        // knob 20: the LDS-DMA fused-spline launches record in-kernel phase stamps (read back with gemm_read_stamps)
+static unsigned long long* g_stamp_buf = nullptr;
+static size_t g_stamp_cap = 0, g_stamp_n = 0;
+size_t gemm_read_stamps(unsigned long long* host, size_t max_n) {
+    FC_HIP(hipDeviceSynchronize());
+    const size_t n = g_stamp_n < max_n ? g_stamp_n : max_n;
+    if (n) FC_HIP(hipMemcpy(host, g_stamp_buf, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return n;
+}
+int g_spline_prefetch = 0;   // knob 21: persistent fused spline GEMM (VAR 11): 1 = a tile's k loop starts at a column-tile dependent step and wraps around (measured: no gain, other summation order); 0 = every tile starts at k = 0 (shipped, bit-identical to VAR 7-10)
+int g_gemm_dma = 4;          // knob 13: fused spline GEMM: 4 = persistent transposed LDS-DMA loop, splines evaluated from the accumulator registers (VAR 11, shipped; K = 8 bins), 3 = the same, one tile per workgroup (VAR 10), 2 = LDS-DMA loop on the 128x128 four-wave tile with the LDS parameter tile (VAR 9), 1 = on the 256x128 tile (VAR 8), 0 = register-staged (VAR 7); bit-identical results
 int g_spline_ablate = 0;     // knob 14: diagnostics, results invalid (1 = no spline evaluation, 2 = main loop only, 3 = no parameter-tile write, 4 = no x2 store, 5 = stop behind the tile write)
 int g_gemm_dma_linear = 2;   // knob 15: limb-image A in a Linear layer: 2 = LDS-DMA loop on the 128x128 four-wave tile (shipped), 1 = on the 256x128 tile, 0 = register-staged
 int g_limb_chain_all = 1;    // knob 16: every hidden activation of the coupling MLP exists only as a limb image (A16 / residual16 / C16)
@@ -843,9 +1200,9 @@ bool Fp16Guard::overflowed() {
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : VAR == 9 ? 2 * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 6 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : VAR == 11 ? 2 * (size_t)(BM + BN) * 128 + 1024 : (VAR == 9 || VAR == 10) ? 2 * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 6 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static bool attr_done = false;
-    constexpr size_t lds_epi = EPI == EPI_SPLINE ? ((size_t)BM * (BN + 1) + (size_t)BM * 9) * sizeof(float) : 0;   // tile + <= 9 dims of log-dets
+    constexpr size_t lds_epi = EPI == EPI_SPLINE && VAR != 10 && VAR != 11 ? ((size_t)BM * (BN + 1) + (size_t)BM * 9) * sizeof(float) : 0;   // tile + <= 9 dims of log-dets
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, EPI, VAR>;
     if (!attr_done) {
@@ -857,10 +1214,35 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
     q.col_group = 0;
     if ((size_t)p.N_pad * p.K_pad * sizeof(float) > (size_t)(3u << 19) && q.nbm % 8 == 0 && q.nbn > g_gemm_colgroup && g_gemm_colgroup > 0)
         q.col_group = g_gemm_colgroup;
+    q.stamps = nullptr;
+    if constexpr (EPI == EPI_SPLINE && (VAR == 8 || VAR == 9 || VAR == 10 || VAR == 11)) {
+        if (g_gemm_stamp) {
+            const size_t n = (size_t)q.nbm * q.nbn * 16;
+            if (n > g_stamp_cap) {
+                if (g_stamp_buf) FC_HIP(hipFree(g_stamp_buf));
+                FC_HIP(hipMalloc(&g_stamp_buf, n * sizeof(unsigned long long)));
+                g_stamp_cap = n;
+            }
+            q.stamps = g_stamp_buf;
+            g_stamp_n = n;
+        }
+    }
     char name[96];
     snprintf(name, sizeof name, "void fc::gemm_f32_kernel<%d, %d, %d, %d, %d, %d>(fc::GemmParams)", BM, BN, WM, WN, EPI, VAR);
     ProfScope ps(name, p.e.flops_hint, 0.0, s);
-    hipLaunchKernelGGL(kern, dim3(q.nbm * q.nbn), dim3(WM * WN * 64), lds, s, q);
+    int grid = q.nbm * q.nbn;
+    if constexpr (VAR == 11) {                                          // persistent: two workgroups per CU, a multiple of 8 (XCD order)
+        static int slots = 0;
+        if (!slots) {
+            int dev = 0, cus = 0;
+            FC_HIP(hipGetDevice(&dev));
+            FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            slots = (2 * cus) & ~7;
+            if (slots < 8) slots = 8;
+        }
+        if (grid > slots) grid = slots;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, q);
     FC_HIP(hipGetLastError());
 }
 
@@ -940,13 +1322,16 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     } else if (epi_kind == EPI_SPLINE) {
         const int K = e.spline_K;
         p.e.inverse = g_spline_ablate;
+        p.e.prefetch_dist = g_spline_prefetch;
         if (!split) throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: the fused spline epilogue exists for the split GEMM loops only");
         if ((K != 4 && K != 8 && K != 16) || L.N_pad != spline_ncols(e.d2, K) || !e.xbuf || !e.ldj_part || e.ldj_pitch < (size_t)rows_alloc)
             throw Error(FC_ERR_INVALID, "launch_gemm: bad fused-spline arguments (layout of spline.h, per-tile log-det buffer)");
         p.nbm = rows_alloc / 128;
         if (f16 && e.A16 && g_gemm_bigtile == 3) {
             if (L.nseg != 1) throw Error(FC_ERR_INVALID, "launch_gemm: a limb-image A operand must be the only segment");
-            if (g_gemm_dma == 2 && L.n_alloc >= round_up(L.N_pad, 128)) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 9>(p, s);
+            if (g_gemm_dma == 4 && K == 8 && L.bias && L.n_alloc >= round_up(L.N_pad, 128)) launch_cfg<128, 128, 4, 1, EPI_SPLINE, 11>(p, s);
+            else if (g_gemm_dma == 3 && K == 8 && L.bias && L.n_alloc >= round_up(L.N_pad, 128)) launch_cfg<128, 128, 4, 1, EPI_SPLINE, 10>(p, s);
+            else if (g_gemm_dma >= 2 && L.n_alloc >= round_up(L.N_pad, 128)) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 9>(p, s);
             else if (g_gemm_dma == 1 && rows_alloc % 256 == 0 && L.n_alloc >= round_up(L.N_pad, 128)) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_SPLINE, 8>(p, s); }
             else launch_cfg<128, 128, 4, 2, EPI_SPLINE, 7>(p, s);
         }

@@ -183,7 +183,14 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const float* __restric
     float* xr = xbuf + (size_t)row * ldx + x2_col0;
     for (int j = lane; j < d2; j += 64) {
         float y, lad;
-        rq_any(K, xr[j], pr + spline_col(j, 0, K), 1, inverse != 0, y, lad);
+        if (K == 8) {                                            // K = 8: register-slot column order (spline.h), gathered per dim
+            float u[25];
+#pragma unroll
+            for (int pp = 0; pp < 25; ++pp) u[pp] = pr[spline_col(j, pp, 8)];
+            rq_spline_elem<8>(xr[j], u, 1, inverse != 0, y, lad);
+        } else {
+            rq_any(K, xr[j], pr + spline_col(j, 0, K), 1, inverse != 0, y, lad);
+        }
         xr[j] = y;
         acc += lad;
     }

@@ -208,7 +208,7 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
     eps = [torch.randn(B, N, 294, generator=g).to(DEV)]
     batch = (e0.to(DEV), e1.to(DEV), None)
-    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 0, 9: 1, 10: 1, 13: 2, 15: 2, 16: 1, 17: 0, 19: 0}
+    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 0, 9: 1, 10: 1, 13: 4, 15: 2, 16: 1, 17: 0, 19: 0, 21: 0}
     try:
         _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
         for name, knobs in (("unfused spline", {7: 0}), ("fused pre-attention chain kernel", {8: 1}), ("separate LayerNorm + q projection", {10: 0}), ("no limb chain", {9: 0}), ("limb chain into the spline GEMM only", {16: 0}), ("limb-chained pre-attention MLP", {19: 1}), ("limb-chained hidden layers on the register-staged tile", {15: 0}), ("limb-chained hidden layers on the 256x128 DMA tile", {15: 1}), ("fp32-input attention", {5: 0}),
@@ -221,13 +221,22 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
             err = (lp - ref).abs().max().item()
             print(f"{name}: max |log-prob - default path| {err:.2e}")
             assert err < 5e-4, name
-        # the LDS-DMA main loop of the fused spline GEMM (256x128 tile, global_load_lds ring) issues the same MFMAs in the same order as
-        # the shipped register-staged loop: bit-identical log-probs
-        for v in (0, 1):
+        # every main loop of the fused spline GEMM issues the same MFMAs in the same k order and hands the same parameters to the same
+        # spline arithmetic: the register-staged loop (0), the LDS-DMA loops with the LDS parameter tile (1: 256x128, 2: 128x128), the
+        # transposed product evaluated from the accumulator registers with one tile per workgroup (3) and the shipped persistent form
+        # (4) give bit-identical log-probs
+        for v in (0, 1, 2, 3):
             lib.fc_debug_set(13, v)
             _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
-            lib.fc_debug_set(13, 2)
-            assert torch.equal(lp, ref), f"fused spline GEMM variant (knob 13 = {v}) differs from the shipped LDS-DMA loop"
+            lib.fc_debug_set(13, 4)
+            print(f"knob 13 = {v}: max |diff| {(lp - ref).abs().max().item():.3e}")
+            assert torch.equal(lp, ref), f"fused spline GEMM variant (knob 13 = {v}) differs from the shipped persistent loop"
+        lib.fc_debug_set(21, 1)                                   # rotated k order: another fp32 summation order, same sums
+        _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+        lib.fc_debug_set(21, 0)
+        err = (lp - ref).abs().max().item()
+        print(f"persistent fused spline GEMM with rotated k loops: max |log-prob - default path| {err:.2e}")
+        assert err < 5e-4
         lib.fc_debug_set(17, 1)                                   # three register sets of prefetch instead of two: same MFMAs, same order
         _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
         lib.fc_debug_set(17, 0)
@@ -235,6 +244,36 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     finally:
         for k, v in defaults.items():
             lib.fc_debug_set(k, v)
+
+
+def test_persistent_spline_gemm_walks_several_tiles_per_workgroup():
+    """The shipped fused spline GEMM is persistent (two workgroups per CU walk the tile list with one continuous DMA stream; results of a
+    tile are stored behind the next tile's first barrier).  18 row tiles x 30 column tiles = 540 tiles > 512 workgroup slots on the
+    plain tile order (row tiles not a multiple of 8), and 24 x 30 = 720 on the column-group order: every tile must come out exactly as
+    from the one-tile-per-workgroup kernels."""
+    from flowcompare_amd import engine
+    lib = engine.lib()
+    for B, N in ((3, 768), (3, 1000)):                             # 2304 rows = 18 tiles; 3000 rows -> 24 tiles, 72 padding rows
+        cfg = fa.named_config("c2_dgcnn_attn_spline", n_flow_layers=2, sample_size=N)
+        torch.manual_seed(21)
+        md = fa.initialize_flow(cfg, device=DEV, mode="test")
+        with torch.no_grad():
+            for name, prm in md["flow"].named_parameters():       # (module init zeroes nothing here, but make the parameter layer lively)
+                if "out_layer" in name:
+                    prm.mul_(3.0)
+        g = torch.Generator().manual_seed(22)
+        e0, e1 = torch.rand(B, 200, 6, generator=g), torch.rand(B, N, 6, generator=g)
+        eps = [torch.randn(B, N, 294, generator=g).to(DEV)]
+        batch = (e0.to(DEV), e1.to(DEV), None)
+        try:
+            _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+            for v in (3, 2):
+                lib.fc_debug_set(13, v)
+                _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+                assert torch.equal(lp, ref), f"{B} x {N}: persistent fused spline GEMM differs from knob 13 = {v}"
+        finally:
+            lib.fc_debug_set(13, 4)
+        assert torch.isfinite(ref).all()
 
 
 def test_c2_layer_widths_with_ragged_sizes_match_the_oracle():
