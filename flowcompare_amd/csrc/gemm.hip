@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void spline_gemm_persistent(const GemmParams& p, floa
         p.stamps[(size_t)t * 16 + 8] = wall_clock64();
     }
     FC_PSTAMP(0)
-    FC_PDMA(src, (e.prefetch_dist != 0 ? (int)(((unsigned)(bn % 10) * (unsigned)p.KT) / 10u) : 0), 0)
+    FC_PDMA(src, (e.prefetch_dist != 0 ? (int)(((unsigned)(bn % 10) * 3u + (unsigned)(bm & 15) * 5u) % (unsigned)p.KT) : 0), 0)
     bias_dma(bn, 0);
     float spl_x[3], spl_ldj;
     load_x(bm, bn, spl_x, spl_ldj);
@@ -1038,14 +1038,14 @@ __device__ __forceinline__ void spline_gemm_persistent(const GemmParams& p, floa
     // therefore starts its k loop at step rot(column tile) and wraps around: the sharers are spread over the panel's k range, each k
     // step is missed by one of them and hit by the others.  fp32 accumulation order changes with it (not bit-identical to VAR 9 / 10).
     const bool rotate = e.prefetch_dist != 0;
-    auto rot_of = [&](int bn_) -> int { return rotate ? (int)(((unsigned)(bn_ % 10) * (unsigned)KT) / 10u) : 0; };
+    auto rot_of = [&](int bm_, int bn_) -> int { return rotate ? (int)(((unsigned)(bn_ % 10) * 3u + (unsigned)(bm_ & 15) * 5u) % (unsigned)KT) : 0; };
     for (;;) {
         const int tn = t + G;
         const bool has_next = tn < ntiles;
         int nbm = 0, nbn = 0;
         if (has_next) tile_of(tn, nbm, nbn);
         float nx[3] = {0.f, 0.f, 0.f}, nldj = 0.f;
-        int kidx = rot_of(bn);                                          // k step being multiplied; the DMA runs one ahead
+        int kidx = rot_of(bm, bn);                                          // k step being multiplied; the DMA runs one ahead
         for (int kt = 0; kt < KT; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of this k step (and anything older) have landed
             __builtin_amdgcn_s_barrier();                               // ... everybody's have; everybody is done reading the other stage
@@ -1054,7 +1054,7 @@ __device__ __forceinline__ void spline_gemm_persistent(const GemmParams& p, floa
                 FC_PDMA(src, kidx, (st ^ 1))
             } else if (has_next) {                                      // the stream runs on into the next tile
                 src = src_of(nbm, nbn);
-                FC_PDMA(src, rot_of(nbn), (st ^ 1))
+                FC_PDMA(src, rot_of(nbm, nbn), (st ^ 1))
                 bias_dma(nbn, par ^ 1);
                 load_x(nbm, nbn, nx, nldj);
             }

@@ -19,7 +19,7 @@ groups=(
 i=0
 for g in "${groups[@]}"; do
   d=/tmp/pmc_$i; rm -rf $d
-  timeout -k 10 150 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $d -o x -- python3 $root/bench.py --layers 8 --steps 1 --warmup 1 --weights module "$@" > /dev/null 2> $root/gpurun_out/${out}_pass$i.err || { echo "pass $i failed" | tee -a $root/gpurun_out/${out}_progress.txt; grep -m1 "exceeds" $root/gpurun_out/${out}_pass$i.err; i=$((i+1)); continue; }
+  timeout -k 10 150 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $d -o x -- python3 $root/bench.py --layers 8 --steps 1 --warmup 1 --weights module --no-cpu-baseline "$@" > /dev/null 2> $root/gpurun_out/${out}_pass$i.err || { echo "pass $i failed" | tee -a $root/gpurun_out/${out}_progress.txt; grep -m1 "exceeds" $root/gpurun_out/${out}_pass$i.err; i=$((i+1)); continue; }
   f=$(find $d -name "x_counter_collection.csv" | head -1)
   python3 $root/profiles/pmc_sq.py $f $root/gpurun_out/${out}_pass$i.json > /dev/null && echo "pass $i ok" | tee -a $root/gpurun_out/${out}_progress.txt
   i=$((i+1))
