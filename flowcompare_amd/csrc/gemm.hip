@@ -714,6 +714,10 @@ void gemm_f32_kernel(const GemmParams p) {
             default: by_fmt(std::integral_constant<int, FC_ACT_NONE>{}); break;
         }
         if (omax >= 65504.0f) atomicOr(p.ovf, 1);                 // (omax stays 0 without a limb-image output)
+        if constexpr (VAR == 8 || VAR == 9) {
+            FC_STAMP(6)
+            if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + 9] = wall_clock64();
+        }
     } else if constexpr (EPI == EPI_LNQ) {
         // ---- LayerNorm folded through the layer (common.h): a wave's 64 columns are either hidden columns (sum of squares per row
         //      into the block's slot) or the 64 q columns (stored un-normalised)
@@ -1215,8 +1219,8 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
     if ((size_t)p.N_pad * p.K_pad * sizeof(float) > (size_t)(3u << 19) && q.nbm % 8 == 0 && q.nbn > g_gemm_colgroup && g_gemm_colgroup > 0)
         q.col_group = g_gemm_colgroup;
     q.stamps = nullptr;
-    if constexpr (EPI == EPI_SPLINE && (VAR == 8 || VAR == 9 || VAR == 10 || VAR == 11)) {
-        if (g_gemm_stamp) {
+    if constexpr ((EPI == EPI_SPLINE || EPI == EPI_LINEAR) && (VAR == 8 || VAR == 9 || VAR == 10 || VAR == 11)) {
+        if (g_gemm_stamp == (EPI == EPI_SPLINE ? 1 : 2)) {                  // knob 20: 1 = the fused spline launches, 2 = the limb-chained Linear launches
             const size_t n = (size_t)q.nbm * q.nbn * 16;
             if (n > g_stamp_cap) {
                 if (g_stamp_buf) FC_HIP(hipFree(g_stamp_buf));

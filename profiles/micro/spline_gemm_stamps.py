@@ -16,7 +16,11 @@ lib = engine.lib()
 lib.fc_debug_gemm_stamps.restype = ctypes.c_int64
 lib.fc_debug_gemm_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int64]
 DEV = torch.device("cuda", 0)
-variants = [int(v) for v in sys.argv[1:]] or [2, 3]
+args = sys.argv[1:]
+which = 2 if args and args[0] == "linear" else 1            # "linear": the limb-chained 512 -> 512 Linear launches (VAR 9) instead
+if which == 2:
+    args = args[1:]
+variants = [int(v) for v in args] or ([4] if which == 2 else [2, 3])
 cfg = fa.named_config("c2_dgcnn_attn_spline", sample_size=4096)
 torch.manual_seed(0)
 md = fa.initialize_flow(cfg, device=DEV, mode="test")
@@ -29,7 +33,7 @@ for v in variants:
     lib.fc_debug_set(13, v)
     lib.fc_debug_set(20, 0)
     fa.inner_loop((e0, e1, None), md, cfg, eps=eps)
-    lib.fc_debug_set(20, 1)
+    lib.fc_debug_set(20, which)
     fa.inner_loop((e0, e1, None), md, cfg, eps=eps)
     torch.cuda.synchronize()
     buf = np.zeros(1 << 21, dtype=np.uint64)
@@ -37,6 +41,8 @@ for v in variants:
     lib.fc_debug_set(20, 0)
     st = buf[:n].reshape(-1, 16).astype(np.int64)
     t = st[:, 0:7]
+    if which == 2:
+        t = t.copy(); t[:, 4] = t[:, 3]; t[:, 5] = t[:, 3]            # (Linear epilogue: one phase, reported under 'stores')
     d = np.diff(t, axis=1)
     wall = (st[:, 9] - st[:, 8]) / 100.0                      # us
     cyc = t[:, 6] - t[:, 0]
