@@ -4,6 +4,7 @@
 #include <memory>
 
 #include "hostpack.h"
+#include "spline.h"
 
 namespace fc {
 
@@ -44,6 +45,11 @@ int fc_debug_set(int32_t key, int32_t value) {
     else return FC_ERR_INVALID;
     return FC_OK;
 }
+
+/* host-side view of the spline parameter layer's column layout (csrc/spline.h) for the CPU tests: column of (transformed dim j, parameter
+   pp) and the dim-major position inside a tile that the LDS-tile epilogues store a column at; no device call */
+int32_t fc_debug_spline_col(int32_t j, int32_t pp, int32_t K) { return fc::spline_col(j, pp, K); }
+int32_t fc_debug_spline_tile_pos(int32_t c, int32_t K) { return fc::spline_tile_pos(c, K); }
 
 /* diagnostic (knob 20): copies the phase stamps of the last stamped fused-spline launch (16 x u64 per workgroup) to host memory; returns the count */
 int64_t fc_debug_gemm_stamps(uint64_t* host, int64_t max_n) {

@@ -90,3 +90,29 @@ def test_no_cpu_fallback():
         md["flow"].transforms[1](batch[1])
     src = "".join(open(os.path.join(ROOT, "flowcompare_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "flowcompare_amd")) if f.endswith(".py"))
     assert "import oracle" not in src and "from oracle" not in src and "flow_oracle" not in src
+
+
+def test_spline_parameter_columns_are_a_bijection_in_register_slot_order():
+    """csrc/spline.h: the 3K+1 parameters of DPT = 128 // (3K+1) transformed dims share a 128-column GEMM tile.  K = 8 packs them in the
+    register-slot order of the transposed MFMA product (dims 0, 1 / 2, 3 in slots 0..49 of the lower / upper half-wave, dim 4 split
+    14 + 11, columns 125..127 unused); K = 4, 16 stay dim-major.  Checks, without a GPU: every (dim, parameter) owns its own column inside
+    its dim's tile, `spline_tile_pos` inverts the mapping to the dim-major position, and the slot arithmetic the kernel relies on."""
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    col, pos = lib.fc_debug_spline_col, lib.fc_debug_spline_tile_pos
+    for K in (4, 8, 16):
+        per, dpt = 3 * K + 1, 128 // (3 * K + 1)
+        for d2 in (1, dpt, dpt + 1, 150):
+            seen = {}
+            for j in range(d2):
+                for pp in range(per):
+                    c = col(j, pp, K)
+                    assert c // 128 == j // dpt and c not in seen, (K, j, pp, c)
+                    seen[c] = (j, pp)
+                    assert pos(c % 128, K) == (j % dpt) * per + pp                 # where the LDS-tile epilogues put that column
+            assert len(seen) == d2 * per
+    # K = 8: slot s of half h is column (s // 16) * 32 + ((s % 16) // 4) * 8 + 4 h + s % 4 (accumulator block, register group, lane half, register)
+    slot_col = lambda s, h: (s // 16) * 32 + ((s % 16) // 4) * 8 + 4 * h + s % 4
+    for dl in range(4):
+        assert [col(dl, pp, 8) for pp in range(25)] == [slot_col((dl & 1) * 25 + pp, dl >> 1) for pp in range(25)]
+    assert [col(4, pp, 8) for pp in range(25)] == [slot_col(50 + pp, 0) for pp in range(14)] + [slot_col(50 + pp, 1) for pp in range(11)]
+    assert sorted(set(range(128)) - {col(j, pp, 8) for j in range(5) for pp in range(25)}) == [125, 126, 127]
