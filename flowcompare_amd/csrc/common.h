@@ -206,7 +206,8 @@ size_t attention_limb_ws_bytes(long kv_rows, int dh_pad);
 // premlp.hip: fused pre-attention MLP -> LayerNorm -> q projection (one launch instead of six) when the shapes allow it
 bool premlp_fusable(const PackedLinear& in, const std::vector<PackedLinear>& mid, const PackedLinear& out, const PackedLinear& q);
 void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::vector<PackedLinear>& mid, const PackedLinear& out,
-                   const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s);
+                   const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s, float* keep_ws = nullptr,
+                   size_t keep_floats = 0);
 // staging.hip: the steps either side of the path
 void launch_fps_nd(const float* pts, int ld, int C, int64_t* idx, int B, int n, int m, float* dist_scratch, hipStream_t s);
 void launch_co_unit_sphere(const float* p0, int n0, const float* p1, int n1, int ld, float* o0, float* o1, float* inverse, int B, hipStream_t s);

@@ -13,6 +13,8 @@
 // Removes per layer: 4 activation round trips through HBM (67 MB written + read each), the LayerNorm pass, 5 launches.
 // Shapes: hidden width = attention input width = 256 exactly, q width 64, input width a multiple of 32 up to 256
 // (the engine falls back to the separate kernels otherwise, and always on the bf16-limb range-fallback pass).
+#include <type_traits>
+
 #include "common.h"
 #include "activations.h"
 
@@ -20,6 +22,9 @@ namespace fc {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+typedef __attribute__((address_space(3))) char pm_lds_char;
+typedef const __attribute__((address_space(1))) char pm_glb_char;
 
 struct PreMlpLayer {
     const unsigned short* W2;   // [n_alloc][K_pad/16][2][16]
@@ -32,6 +37,7 @@ struct PreMlpParams {
     int act;
     float* qout; int ldq;
     int rows;                           // rows allocated (multiple of 64)
+    float* keep_ws;                     // row-resident kernel: rows x 256 floats of scratch (the second hidden layer's residual, parked as limb fragments)
     int* ovf;
 };
 
@@ -237,6 +243,251 @@ __global__ __launch_bounds__(PM_NT) __attribute__((amdgpu_waves_per_eu(2))) void
     if (amax >= 65504.0f) atomicOr(p.ovf, 1);
 }
 
+// =====================================================================================================================================
+// Row-resident variant (knob 8 = 2): the chain's activations never leave the REGISTERS.
+//   The product is transposed (weights as the MFMA's A operand, points as B) on the 16x16x32 shape: a wave owns 16 points, a point is
+//   spread over the four lanes n, n + 16, n + 32, n + 48 (lane row kg = lane >> 4 supplies in-features 32 s + 8 kg + 0..7 of k step s).
+//   Per lane: the layer's input as B-operand fragments (8 k steps x [hi | lo'] x 8 fp16 = 64 registers), the output being assembled in
+//   the same form (64, sharing registers with the residual of the second hidden layer as that is consumed), one 32-feature accumulator
+//   chunk (16) -- about 200 registers, so eight waves (128 rows) run two per SIMD.  Between layers nothing is stored anywhere: an
+//   output chunk goes from the accumulator's order (lane row kg holds features 16 mb + 4 kg + i) to the operand order (features
+//   8 kg + e of the chunk) with one `v_permlane32_swap` + one `v_permlane16_swap` per register pair, gets bias / residual / activation
+//   and is split into limbs in place.  LayerNorm is an in-lane sum plus two cross-row adds.
+//   Only the weights move: a chunk = 32 out-features x K as one LDS stage (32 KB at K = 256: a 1 KiB DMA piece is one weight row;
+//   16-byte chunks XOR-swizzled by (row & 15) on the source address and on the read), two stages, 48 MFMAs per wave and barrier.
+//   The 1.3 MB of weights are streamed once per 128 rows (the LDS-tile kernel above: per 64) and, with no activation tile in LDS, a
+//   stage is 4x as long per barrier.
+constexpr int PR_ROWS = 128, PR_NT = 512, PR_CH = 32;
+constexpr int PR_BUF = PR_CH * PM_H * 4;                    // 32 KB: one chunk of 32 weight rows at K = 256
+constexpr int PR_BIAS_OFF = 2 * PR_BUF;                     // [5][256] floats: in, mid0, mid1, out, q
+constexpr int PR_LDS = PR_BIAS_OFF + 5 * PM_H * 4;
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// rows of 16 lanes (a0,a1,a2,a3 | b0,b1,b2,b3):  swap32 -> a = (a0,a1,b0,b1), b = (a2,a3,b2,b3) ;  swap16 -> a = (a0,b0,a2,b2), b = (a1,b1,a3,b3)
+__device__ __forceinline__ void pr_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void pr_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+
+// DMA of chunk c (weight rows 32 c .. 32 c + 31, all K) of layer L into `dst`: 1 KiB pieces dealt round-robin to the eight waves
+__device__ __forceinline__ void pr_dma(const PreMlpLayer& L, int c, char* dst, int wave, int lane) {
+    const int cpr = L.K_pad >> 2;                            // 16-byte chunks per weight row (64 at K = 256, 40 at K = 160)
+    const int sw = (cpr & 15) == 0 ? 15 : 7;
+    const int npieces = cpr >> 1;                            // 32 rows * cpr chunks / 64 lanes
+    const char* base = reinterpret_cast<const char*>(L.W2) + (size_t)c * PR_CH * cpr * 16;
+    for (int pc = wave; pc < npieces; pc += 8) {
+        const int ci = pc * 64 + lane;
+        const int r = cpr == 64 ? ci >> 6 : ci / cpr;
+        const int q = ci - r * cpr;
+        __builtin_amdgcn_global_load_lds((pm_glb_char*)(base + ((size_t)r * cpr + (q ^ (r & sw))) * 16), (pm_lds_char*)(dst + pc * 1024), 16, 0, 0);
+    }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void premlp_rows_kernel(const PreMlpParams p) {
+    extern __shared__ float smem[];
+    char* smc = reinterpret_cast<char*>(smem);
+    float* biasbuf = reinterpret_cast<float*>(smc + PR_BIAS_OFF);
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = blockIdx.x * PR_ROWS + wave * 16 + n;
+    float amax = 0.f;
+
+    // biases of the five layers -> LDS (the epilogues read them as broadcasts)
+    if (tid < PM_H) {
+        const PreMlpLayer* Ls[5] = {&p.in, &p.mid0, &p.mid1, &p.out, &p.q};
+#pragma unroll
+        for (int l = 0; l < 5; ++l) biasbuf[l * PM_H + tid] = (Ls[l]->bias && (l < 4 || tid < 64)) ? Ls[l]->bias[tid] : 0.f;
+    }
+    pr_dma(p.in, 0, smc, wave, lane);
+
+    f16x8 ah[8], al[8], nh[8], nl[8];
+    // the residual of the second hidden layer (= the in_layer's output) is parked in global scratch while hidden layer 0 runs -- 64 registers
+    // this kernel does not have: fragment (s, limb) of lane tid at keep_frag[(s * 2 + limb) * 512 + tid], 1 KiB per wave instruction
+    uint4* keep_frag = reinterpret_cast<uint4*>(p.keep_ws) + (size_t)blockIdx.x * 16 * PR_NT + tid;
+    // ---- input row -> operand fragments: lane (n, kg) supplies features 32 s + 8 kg + 0..7 of its point
+    {
+        const int KS = p.in.K_pad >> 5;
+        const float* xr = p.x + (size_t)row * p.ldx + 8 * kg;
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            float xs[8];
+            if (s_ < KS) {
+                const float4 x0 = *reinterpret_cast<const float4*>(xr + 32 * s_), x1 = *reinterpret_cast<const float4*>(xr + 32 * s_ + 4);
+                xs[0] = x0.x; xs[1] = x0.y; xs[2] = x0.z; xs[3] = x0.w; xs[4] = x1.x; xs[5] = x1.y; xs[6] = x1.z; xs[7] = x1.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xs[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                amax = fmaxf(amax, fabsf(xs[e]));
+                const _Float16 h = (_Float16)xs[e];
+                ah[s_][e] = h;
+                al[s_][e] = (_Float16)((xs[e] - (float)h) * 2048.0f);
+            }
+        }
+    }
+    __syncthreads();                                         // biasbuf visible
+
+    int buf = 0;                                             // stage that holds (is receiving) the chunk about to be multiplied
+
+    // MFMAs of one chunk: (am, ac) = W[32 c .. 32 c + 31][:] . act  (main / cross-product accumulators of the two 16-feature blocks)
+    auto chunk_mma = [&](const PreMlpLayer& L, const PreMlpLayer* nextL, int nextc, bool full_k, floatx4 (&am)[2], floatx4 (&ac)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { am[mb][i] = 0.f; ac[mb][i] = 0.f; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // own pieces of this chunk have landed
+        __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
+        if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PR_BUF, wave, lane);
+        const int cpr = L.K_pad >> 2, KS = L.K_pad >> 5;
+        const int sw = (cpr & 15) == 0 ? n : (n & 7);
+        const char* wrow = smc + buf * PR_BUF + n * cpr * 16;
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            if (full_k || s_ < KS) {
+                const int ch = 4 * (2 * s_ + (kg >> 1)) + (kg & 1);      // 16-byte chunk of this lane's 8 k values (hi limb; lo' = + 2)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const char* wr = wrow + mb * 16 * cpr * 16;
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(wr + ((ch) ^ sw) * 16);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(wr + ((ch + 2) ^ sw) * 16);
+                    am[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[s_], am[mb], 0, 0, 0);
+                    ac[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[s_], ac[mb], 0, 0, 0);
+                    ac[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[s_], ac[mb], 0, 0, 0);
+                }
+            }
+        }
+        buf ^= 1;
+    };
+    // accumulator order (block mb, register i = feature 16 mb + 4 kg + i) -> operand order: t[e] = out-feature 32 c + 8 kg + e (before bias)
+    auto fold = [&](const floatx4 (&am)[2], const floatx4 (&ac)[2], float (&t)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float P = am[0][i] + ac[0][i] * (1.0f / 2048.0f), Q = am[1][i] + ac[1][i] * (1.0f / 2048.0f);
+            pr_swap32(P, Q);
+            pr_swap16(P, Q);
+            t[i] = P;
+            t[4 + i] = Q;
+        }
+    };
+    // bias, residual, activation, limb split of one chunk, pushed into the output FIFO nh / nl (slot 7 after a shift by one: every
+    // chunk then runs the SAME code, so a layer is a loop of ~4 KB instead of 30 KB of straight-line code -- unrolled, the kernel
+    // streamed 90 KB of instructions once per workgroup through a 64 KB instruction cache).  Flags are compile-time: straight-line
+    // code the scheduler lays under the NEXT chunk's MFMAs (8 values x ~35 VALU instructions per lane and chunk are as much issue time
+    // as the chunk's 48 MFMAs).
+    auto epilogue = [&](const float (&t)[8], const f16x8& rh, const f16x8& rl, int bias_off, auto resid_tag, auto act_tag) __attribute__((always_inline)) {
+        constexpr bool RESID = decltype(resid_tag)::value;
+        constexpr int A = decltype(act_tag)::value;
+        const float* bp = biasbuf + bias_off + 8 * kg;
+        const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+        const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int b = 0; b < 7; ++b) { nh[b] = nh[b + 1]; nl[b] = nl[b + 1]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = t[e] + bs[e];
+            if constexpr (RESID) x += (float)rh[e] + (float)rl[e] * (1.0f / 2048.0f);
+            if constexpr (A == FC_ACT_GELU) x = fc_gelu(x);
+            else if constexpr (A == FC_ACT_RELU) x = x > 0.f ? x : 0.f;
+            else if constexpr (A == FC_ACT_ELU) x = x > 0.f ? x : expm1f(x);
+            else if constexpr (A == FC_ACT_LRELU02) x = x > 0.f ? x : 0.2f * x;
+            amax = fmaxf(amax, fabsf(x));
+            const _Float16 h = (_Float16)x;
+            nh[7][e] = h;
+            nl[7][e] = (_Float16)((x - (float)h) * 2048.0f);
+        }
+    };
+    // one layer, software-pipelined: iteration c issues the MFMAs of chunk c and, behind them in the same basic block, the epilogue of
+    // chunk c - 1 (iteration 0 pushes a dummy that the eight real pushes shift out again)
+    auto layer = [&](const PreMlpLayer& L, const PreMlpLayer& nextL, int lidx, auto fullk_tag, auto resid_tag, auto act_tag) __attribute__((always_inline)) {
+        constexpr bool FULLK = decltype(fullk_tag)::value;
+        constexpr bool RESID = decltype(resid_tag)::value;
+        float tp[8];
+        f16x8 rph, rpl, rch, rcl;                                       // residual fragments of the previous / this chunk
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { tp[e] = 0.f; rph[e] = 0; rpl[e] = 0; rch[e] = 0; rcl[e] = 0; }
+#pragma unroll 1
+        for (int c = 0; c < 8; ++c) {
+            floatx4 am[2], ac[2];
+            if constexpr (RESID) {
+                rch = __builtin_bit_cast(f16x8, keep_frag[(2 * c) * PR_NT]);
+                rcl = __builtin_bit_cast(f16x8, keep_frag[(2 * c + 1) * PR_NT]);
+            }
+            chunk_mma(L, c + 1 < 8 ? &L : &nextL, c + 1 < 8 ? c + 1 : 0, FULLK, am, ac);
+            epilogue(tp, rph, rpl, lidx * PM_H + 32 * (c > 0 ? c - 1 : 0), resid_tag, act_tag);
+            fold(am, ac, tp);
+            rph = rch; rpl = rcl;
+        }
+        epilogue(tp, rph, rpl, lidx * PM_H + 32 * 7, resid_tag, act_tag);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { ah[b] = nh[b]; al[b] = nl[b]; }
+    };
+    using ActT = std::integral_constant<int, ACT>; using NoAct = std::integral_constant<int, FC_ACT_NONE>;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { nh[b][e] = 0; nl[b][e] = 0; }
+    // ---- in_layer, hidden layer 0 (keep = x; x = act(W x)), hidden layer 1 (x = act(keep + W x)), out_layer (no activation)
+    layer(p.in, p.mid0, 0, std::false_type{}, std::false_type{}, ActT{});
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        keep_frag[(2 * b) * PR_NT] = __builtin_bit_cast(uint4, ah[b]);
+        keep_frag[(2 * b + 1) * PR_NT] = __builtin_bit_cast(uint4, al[b]);
+    }
+    layer(p.mid0, p.mid1, 1, std::true_type{}, std::false_type{}, ActT{});
+    layer(p.mid1, p.out, 2, std::true_type{}, std::true_type{}, ActT{});
+    layer(p.out, p.q, 3, std::true_type{}, std::false_type{}, NoAct{});
+
+    // ---- LayerNorm over the 256 features of the point (biased variance, eps 1e-5; gamma / beta live in the q projection): the four
+    //      lanes of a point hold 64 features each, as limbs (x = hi + lo'/2048 to 2^-24)
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)ah[b][e] + (float)al[b][e] * (1.0f / 2048.0f);
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / PM_H);
+        float sq = 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dlt = ((float)ah[b][e] + (float)al[b][e] * (1.0f / 2048.0f)) - mean;
+                sq += dlt * dlt;
+            }
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / PM_H) + 1e-5f);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = (((float)ah[b][e] + (float)al[b][e] * (1.0f / 2048.0f)) - mean) * rstd;
+                amax = fmaxf(amax, fabsf(x));
+                const _Float16 h = (_Float16)x;
+                ah[b][e] = h;
+                al[b][e] = (_Float16)((x - (float)h) * 2048.0f);
+            }
+    }
+
+    // ---- q projection 256 -> 64: two chunks; the lane stores 8 consecutive columns of its row
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        floatx4 am[2], ac[2];
+        float t[8];
+        chunk_mma(p.q, c == 0 ? &p.q : nullptr, 1, true, am, ac);
+        fold(am, ac, t);
+        const float* bp = biasbuf + 4 * PM_H + 32 * c + 8 * kg;
+        const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+        float* qp = p.qout + (size_t)row * p.ldq + 32 * c + 8 * kg;
+        *reinterpret_cast<float4*>(qp) = make_float4(t[0] + b0.x, t[1] + b0.y, t[2] + b0.z, t[3] + b0.w);
+        *reinterpret_cast<float4*>(qp + 4) = make_float4(t[4] + b1.x, t[5] + b1.y, t[6] + b1.z, t[7] + b1.w);
+    }
+    if (amax >= 65504.0f) atomicOr(p.ovf, 1);
+}
+
 int g_premlp_fused = 0;       // tuning knob (fc_debug_set 8).  OFF by default: this kernel beat the six launches it replaces by 8 % when it was
                               // written, but the eight-wave GEMM tile and the cheaper GELU then made the separate kernels 2 % faster
                               // end to end (one 64-row workgroup per CU re-streams every layer's weights from L2: 16 % MFMA busy)
@@ -255,7 +506,7 @@ bool premlp_fusable(const PackedLinear& in, const std::vector<PackedLinear>& mid
 }
 
 void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::vector<PackedLinear>& mid, const PackedLinear& out,
-                   const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s) {
+                   const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s, float* keep_ws, size_t keep_floats) {
     if (rows_alloc % PM_ROWS != 0 || ldx % 4 != 0 || ldx < in.K_pad || ((uintptr_t)x & 15))
         throw Error(FC_ERR_INVALID, "premlp: rows must be padded to 64, input pitch to 4 floats");
     static bool attr_done = false;
@@ -267,9 +518,26 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
     p.x = x; p.ldx = ldx;
     auto L = [](const PackedLinear& l) { return PreMlpLayer{l.W2, l.bias, l.K_pad}; };
     p.in = L(in); p.mid0 = L(mid[0]); p.mid1 = L(mid[1]); p.out = L(out); p.q = L(q);
-    p.act = act; p.qout = qout; p.ldq = ldq; p.rows = rows_alloc; p.ovf = gemm_fp16_flag();
+    p.act = act; p.qout = qout; p.ldq = ldq; p.rows = rows_alloc; p.ovf = gemm_fp16_flag(); p.keep_ws = keep_ws;
     const double rv = rows_valid > 0 ? rows_valid : rows_alloc;
     const double flops = 2.0 * rv * ((double)in.k_true * PM_H + 3.0 * PM_H * PM_H + (double)PM_H * (q.n_true ? q.n_true : 64));
+    if (g_premlp_fused == 2 && rows_alloc % PR_ROWS == 0 && ldq % 4 == 0 && ((uintptr_t)qout & 15) == 0 && keep_ws && ((uintptr_t)keep_ws & 15) == 0 &&
+        keep_floats >= (size_t)rows_alloc * PM_H) {
+        auto go = [&](auto kern) {
+            FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS));
+            ProfScope ps("fc::premlp_rows_kernel(fc::PreMlpParams)", flops, 0.0, s);
+            hipLaunchKernelGGL(kern, dim3(rows_alloc / PR_ROWS), dim3(PR_NT), PR_LDS, s, p);
+            FC_HIP(hipGetLastError());
+        };
+        switch (act) {
+            case FC_ACT_GELU: go(premlp_rows_kernel<FC_ACT_GELU>); break;
+            case FC_ACT_RELU: go(premlp_rows_kernel<FC_ACT_RELU>); break;
+            case FC_ACT_ELU: go(premlp_rows_kernel<FC_ACT_ELU>); break;
+            case FC_ACT_LRELU02: go(premlp_rows_kernel<FC_ACT_LRELU02>); break;
+            default: go(premlp_rows_kernel<FC_ACT_NONE>); break;
+        }
+        return;
+    }
     ProfScope ps("fc::premlp_kernel(fc::PreMlpParams)", flops, 0.0, s);
     hipLaunchKernelGGL(premlp_kernel, dim3(rows_alloc / PM_ROWS), dim3(PM_NT), PM_LDS, s, p);
     FC_HIP(hipGetLastError());
