@@ -331,7 +331,8 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     int buf = 0;                                             // stage that holds (is receiving) the chunk about to be multiplied
 
     // MFMAs of one chunk: (am, ac) = W[32 c .. 32 c + 31][:] . act  (main / cross-product accumulators of the two 16-feature blocks)
-    auto chunk_mma = [&](const PreMlpLayer& L, const PreMlpLayer* nextL, int nextc, bool full_k, floatx4 (&am)[2], floatx4 (&ac)[2]) __attribute__((always_inline)) {
+    auto chunk_mma = [&](const PreMlpLayer& L, const PreMlpLayer* nextL, int nextc, auto fullk_tag, floatx4 (&am)[2], floatx4 (&ac)[2]) __attribute__((always_inline)) {
+        constexpr bool full_k = decltype(fullk_tag)::value;           // compile-time: the k loop of a 256-wide layer is ONE basic block
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 rch = __builtin_bit_cast(f16x8, keep_frag[(2 * c) * PR_NT]);
                 rcl = __builtin_bit_cast(f16x8, keep_frag[(2 * c + 1) * PR_NT]);
             }
-            chunk_mma(L, c + 1 < 8 ? &L : &nextL, c + 1 < 8 ? c + 1 : 0, FULLK, am, ac);
+            chunk_mma(L, c + 1 < 8 ? &L : &nextL, c + 1 < 8 ? c + 1 : 0, fullk_tag, am, ac);
             epilogue(tp, rph, rpl, lidx * PM_H + 32 * (c > 0 ? c - 1 : 0), resid_tag, act_tag);
             fold(am, ac, tp);
             rph = rch; rpl = rcl;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     for (int c = 0; c < 2; ++c) {
         floatx4 am[2], ac[2];
         float t[8];
-        chunk_mma(p.q, c == 0 ? &p.q : nullptr, 1, true, am, ac);
+        chunk_mma(p.q, c == 0 ? &p.q : nullptr, 1, std::true_type{}, am, ac);
         fold(am, ac, t);
         const float* bp = biasbuf + 4 * PM_H + 32 * c + 8 * kg;
         const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
@@ -488,9 +489,9 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     if (amax >= 65504.0f) atomicOr(p.ovf, 1);
 }
 
-int g_premlp_fused = 0;       // tuning knob (fc_debug_set 8).  OFF by default: this kernel beat the six launches it replaces by 8 % when it was
-                              // written, but the eight-wave GEMM tile and the cheaper GELU then made the separate kernels 2 % faster
-                              // end to end (one 64-row workgroup per CU re-streams every layer's weights from L2: 16 % MFMA busy)
+int g_premlp_fused = 2;       // tuning knob (fc_debug_set 8): 2 = the row-resident kernel (activations in registers; shipped: 190 us against ~250 us for the
+                              // five launches it replaces, -1.4 ... -2 % per C2 step), 1 = the LDS-tile kernel (263 us: one 64-row workgroup per CU
+                              // re-streams every layer's weights from L2, 16 % MFMA busy), 0 = separate GEMM launches + the LayerNorm -> q fold
 
 static bool premlp_layer_ok(const PackedLinear& L, int n, int kmax) {
     return L.W2 != nullptr && L.bias != nullptr && L.nseg == 1 && L.N_pad == n && L.n_true == n && L.K_pad % 32 == 0 && L.K_pad <= kmax &&

@@ -208,10 +208,10 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
     eps = [torch.randn(B, N, 294, generator=g).to(DEV)]
     batch = (e0.to(DEV), e1.to(DEV), None)
-    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 0, 9: 1, 10: 1, 13: 4, 15: 2, 16: 1, 17: 0, 19: 0, 21: 0}
+    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 2, 9: 1, 10: 1, 13: 4, 15: 2, 16: 1, 17: 0, 19: 0, 21: 0}
     try:
         _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
-        for name, knobs in (("unfused spline", {7: 0}), ("fused pre-attention chain kernel", {8: 1}), ("row-resident pre-attention chain kernel (activations in registers)", {8: 2}), ("separate LayerNorm + q projection", {10: 0}), ("no limb chain", {9: 0}), ("limb chain into the spline GEMM only", {16: 0}), ("limb-chained pre-attention MLP", {19: 1}), ("limb-chained hidden layers on the register-staged tile", {15: 0}), ("limb-chained hidden layers on the 256x128 DMA tile", {15: 1}), ("fp32-input attention", {5: 0}),
+        for name, knobs in (("unfused spline", {7: 0}), ("LDS-tile pre-attention chain kernel", {8: 1}), ("separate pre-attention GEMM launches + LayerNorm -> q fold", {8: 0}), ("separate LayerNorm + q projection", {8: 0, 10: 0}), ("no limb chain", {9: 0}), ("limb chain into the spline GEMM only", {16: 0}), ("limb-chained pre-attention MLP", {8: 0, 19: 1}), ("limb-chained hidden layers on the register-staged tile", {15: 0}), ("limb-chained hidden layers on the 256x128 DMA tile", {15: 1}), ("fp32-input attention", {5: 0}),
                             ("four-wave tile", {3: 0}), ("256x128 tile", {3: 2}), ("bf16-limb GEMM", {0: 3}), ("fp32-input MFMA GEMM", {0: 2})):
             for k, v in knobs.items():
                 lib.fc_debug_set(k, v)
