@@ -1162,6 +1162,15 @@ int g_gemm_variant = 5, g_gemm_colgroup = 10, g_gemm_bigtile = 3, g_limb_chain =
 int g_gemm_stamp = 0;        // knob 20: the LDS-DMA fused-spline launches record in-kernel phase stamps (read back with gemm_read_stamps)
 static unsigned long long* g_stamp_buf = nullptr;
 static size_t g_stamp_cap = 0, g_stamp_n = 0;
+unsigned long long* gemm_stamp_buffer(size_t n) {
+    if (n > g_stamp_cap) {
+        if (g_stamp_buf) FC_HIP(hipFree(g_stamp_buf));
+        FC_HIP(hipMalloc(&g_stamp_buf, n * sizeof(unsigned long long)));
+        g_stamp_cap = n;
+    }
+    g_stamp_n = n;
+    return g_stamp_buf;
+}
 size_t gemm_read_stamps(unsigned long long* host, size_t max_n) {
     FC_HIP(hipDeviceSynchronize());
     const size_t n = g_stamp_n < max_n ? g_stamp_n : max_n;

@@ -37,6 +37,7 @@ struct PreMlpParams {
     int act;
     float* qout; int ldq;
     int rows;                           // rows allocated (multiple of 64)
+    unsigned long long* stamps;         // diagnostic knob 20 = 3: 16 x u64 per workgroup (s_memtime at the layer boundaries; wall clock in 14 / 15)
     float* keep_ws;                     // row-resident kernel: rows x 256 floats of scratch (the second hidden layer's residual, parked as limb fragments)
     int* ovf;
 };
@@ -281,7 +282,9 @@ __device__ __forceinline__ void pr_dma(const PreMlpLayer& L, int c, char* dst, i
     }
 }
 
-template <int ACT>
+// KSIN: the in_layer's number of 32-wide k steps when known at compile time (its k loop is then one basic block like the 256-wide
+// layers'), 0 = read it from the layer (branches per k step)
+template <int ACT, int KSIN>
 __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void premlp_rows_kernel(const PreMlpParams p) {
     extern __shared__ float smem[];
     char* smc = reinterpret_cast<char*>(smem);
@@ -291,6 +294,14 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int row = blockIdx.x * PR_ROWS + wave * 16 + n;
     float amax = 0.f;
 
+#define PR_STAMP(K_)                                                                                                  \
+    if (p.stamps && threadIdx.x == 0) {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        p.stamps[(size_t)blockIdx.x * 16 + (K_)] = __builtin_amdgcn_s_memtime();                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + 14] = wall_clock64();
+    PR_STAMP(0)
     // biases of the five layers -> LDS (the epilogues read them as broadcasts)
     if (tid < PM_H) {
         const PreMlpLayer* Ls[5] = {&p.in, &p.mid0, &p.mid1, &p.out, &p.q};
@@ -327,12 +338,13 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         }
     }
     __syncthreads();                                         // biasbuf visible
+    PR_STAMP(1)
 
     int buf = 0;                                             // stage that holds (is receiving) the chunk about to be multiplied
 
     // MFMAs of one chunk: (am, ac) = W[32 c .. 32 c + 31][:] . act  (main / cross-product accumulators of the two 16-feature blocks)
-    auto chunk_mma = [&](const PreMlpLayer& L, const PreMlpLayer* nextL, int nextc, auto fullk_tag, floatx4 (&am)[2], floatx4 (&ac)[2]) __attribute__((always_inline)) {
-        constexpr bool full_k = decltype(fullk_tag)::value;           // compile-time: the k loop of a 256-wide layer is ONE basic block
+    auto chunk_mma = [&](const PreMlpLayer& L, const PreMlpLayer* nextL, int nextc, auto fullk_tag, floatx4 (&am)[2], floatx4 (&ac)[2], auto&& after_dma) __attribute__((always_inline)) {
+        constexpr int KSTAT = decltype(fullk_tag)::value;             // compile-time k steps (8 for the 256-wide layers): the k loop is ONE basic block; 0 = run time
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -340,12 +352,13 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // own pieces of this chunk have landed
         __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
         if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PR_BUF, wave, lane);
+        after_dma();                                                    // (loads that must not sit in front of the wait above: they get this chunk's time to land)
         const int cpr = L.K_pad >> 2, KS = L.K_pad >> 5;
         const int sw = (cpr & 15) == 0 ? n : (n & 7);
         const char* wrow = smc + buf * PR_BUF + n * cpr * 16;
 #pragma unroll
         for (int s_ = 0; s_ < 8; ++s_) {
-            if (full_k || s_ < KS) {
+            if (KSTAT ? s_ < KSTAT : s_ < KS) {
                 const int ch = 4 * (2 * s_ + (kg >> 1)) + (kg & 1);      // 16-byte chunk of this lane's 8 k values (hi limb; lo' = + 2)
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
@@ -401,7 +414,6 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // one layer, software-pipelined: iteration c issues the MFMAs of chunk c and, behind them in the same basic block, the epilogue of
     // chunk c - 1 (iteration 0 pushes a dummy that the eight real pushes shift out again)
     auto layer = [&](const PreMlpLayer& L, const PreMlpLayer& nextL, int lidx, auto fullk_tag, auto resid_tag, auto act_tag) __attribute__((always_inline)) {
-        constexpr bool FULLK = decltype(fullk_tag)::value;
         constexpr bool RESID = decltype(resid_tag)::value;
         float tp[8];
         f16x8 rph, rpl, rch, rcl;                                       // residual fragments of the previous / this chunk
@@ -410,11 +422,12 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll 1
         for (int c = 0; c < 8; ++c) {
             floatx4 am[2], ac[2];
-            if constexpr (RESID) {
-                rch = __builtin_bit_cast(f16x8, keep_frag[(2 * c) * PR_NT]);
-                rcl = __builtin_bit_cast(f16x8, keep_frag[(2 * c + 1) * PR_NT]);
-            }
-            chunk_mma(L, c + 1 < 8 ? &L : &nextL, c + 1 < 8 ? c + 1 : 0, fullk_tag, am, ac);
+            chunk_mma(L, c + 1 < 8 ? &L : &nextL, c + 1 < 8 ? c + 1 : 0, fullk_tag, am, ac, [&]() __attribute__((always_inline)) {
+                if constexpr (RESID) {
+                    rch = __builtin_bit_cast(f16x8, keep_frag[(2 * c) * PR_NT]);
+                    rcl = __builtin_bit_cast(f16x8, keep_frag[(2 * c + 1) * PR_NT]);
+                }
+            });
             epilogue(tp, rph, rpl, lidx * PM_H + 32 * (c > 0 ? c - 1 : 0), resid_tag, act_tag);
             fold(am, ac, tp);
             rph = rch; rpl = rcl;
@@ -429,15 +442,19 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
         for (int e = 0; e < 8; ++e) { nh[b][e] = 0; nl[b][e] = 0; }
     // ---- in_layer, hidden layer 0 (keep = x; x = act(W x)), hidden layer 1 (x = act(keep + W x)), out_layer (no activation)
-    layer(p.in, p.mid0, 0, std::false_type{}, std::false_type{}, ActT{});
+    layer(p.in, p.mid0, 0, std::integral_constant<int, KSIN>{}, std::false_type{}, ActT{});
+    PR_STAMP(2)
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         keep_frag[(2 * b) * PR_NT] = __builtin_bit_cast(uint4, ah[b]);
         keep_frag[(2 * b + 1) * PR_NT] = __builtin_bit_cast(uint4, al[b]);
     }
-    layer(p.mid0, p.mid1, 1, std::true_type{}, std::false_type{}, ActT{});
-    layer(p.mid1, p.out, 2, std::true_type{}, std::true_type{}, ActT{});
-    layer(p.out, p.q, 3, std::true_type{}, std::false_type{}, NoAct{});
+    layer(p.mid0, p.mid1, 1, std::integral_constant<int, 8>{}, std::false_type{}, ActT{});
+    PR_STAMP(3)
+    layer(p.mid1, p.out, 2, std::integral_constant<int, 8>{}, std::true_type{}, ActT{});
+    PR_STAMP(4)
+    layer(p.out, p.q, 3, std::integral_constant<int, 8>{}, std::false_type{}, NoAct{});
+    PR_STAMP(5)
 
     // ---- LayerNorm over the 256 features of the point (biased variance, eps 1e-5; gamma / beta live in the q projection): the four
     //      lanes of a point hold 64 features each, as limbs (x = hi + lo'/2048 to 2^-24)
@@ -473,12 +490,13 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             }
     }
 
+    PR_STAMP(6)
     // ---- q projection 256 -> 64: two chunks; the lane stores 8 consecutive columns of its row
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         floatx4 am[2], ac[2];
         float t[8];
-        chunk_mma(p.q, c == 0 ? &p.q : nullptr, 1, std::true_type{}, am, ac);
+        chunk_mma(p.q, c == 0 ? &p.q : nullptr, 1, std::integral_constant<int, 8>{}, am, ac, []() {});
         fold(am, ac, t);
         const float* bp = biasbuf + 4 * PM_H + 32 * c + 8 * kg;
         const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
@@ -487,6 +505,9 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         *reinterpret_cast<float4*>(qp + 4) = make_float4(t[4] + b1.x, t[5] + b1.y, t[6] + b1.z, t[7] + b1.w);
     }
     if (amax >= 65504.0f) atomicOr(p.ovf, 1);
+    PR_STAMP(7)
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = wall_clock64();
+#undef PR_STAMP
 }
 
 int g_premlp_fused = 2;       // tuning knob (fc_debug_set 8): 2 = the row-resident kernel (activations in registers; shipped: 190 us against ~250 us for the
@@ -506,6 +527,9 @@ bool premlp_fusable(const PackedLinear& in, const std::vector<PackedLinear>& mid
            q.K_pad == PM_H && q.k_true == PM_H;
 }
 
+extern int g_gemm_stamp;
+unsigned long long* gemm_stamp_buffer(size_t n);      // gemm.hip: the knob-20 stamp buffer (grown on demand), read back by fc_debug_gemm_stamps
+
 void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::vector<PackedLinear>& mid, const PackedLinear& out,
                    const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s, float* keep_ws, size_t keep_floats) {
     if (rows_alloc % PM_ROWS != 0 || ldx % 4 != 0 || ldx < in.K_pad || ((uintptr_t)x & 15))
@@ -520,6 +544,7 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
     auto L = [](const PackedLinear& l) { return PreMlpLayer{l.W2, l.bias, l.K_pad}; };
     p.in = L(in); p.mid0 = L(mid[0]); p.mid1 = L(mid[1]); p.out = L(out); p.q = L(q);
     p.act = act; p.qout = qout; p.ldq = ldq; p.rows = rows_alloc; p.ovf = gemm_fp16_flag(); p.keep_ws = keep_ws;
+    p.stamps = g_gemm_stamp == 3 ? gemm_stamp_buffer((size_t)(rows_alloc / PR_ROWS) * 16) : nullptr;
     const double rv = rows_valid > 0 ? rows_valid : rows_alloc;
     const double flops = 2.0 * rv * ((double)in.k_true * PM_H + 3.0 * PM_H * PM_H + (double)PM_H * (q.n_true ? q.n_true : 64));
     if (g_premlp_fused == 2 && rows_alloc % PR_ROWS == 0 && ldq % 4 == 0 && ((uintptr_t)qout & 15) == 0 && keep_ws && ((uintptr_t)keep_ws & 15) == 0 &&
@@ -530,12 +555,13 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
             hipLaunchKernelGGL(kern, dim3(rows_alloc / PR_ROWS), dim3(PR_NT), PR_LDS, s, p);
             FC_HIP(hipGetLastError());
         };
+        const bool k5 = in.K_pad == 160;                                // latent 300: x1 = 150 columns (the shipped configurations)
         switch (act) {
-            case FC_ACT_GELU: go(premlp_rows_kernel<FC_ACT_GELU>); break;
-            case FC_ACT_RELU: go(premlp_rows_kernel<FC_ACT_RELU>); break;
-            case FC_ACT_ELU: go(premlp_rows_kernel<FC_ACT_ELU>); break;
-            case FC_ACT_LRELU02: go(premlp_rows_kernel<FC_ACT_LRELU02>); break;
-            default: go(premlp_rows_kernel<FC_ACT_NONE>); break;
+            case FC_ACT_GELU: k5 ? go(premlp_rows_kernel<FC_ACT_GELU, 5>) : go(premlp_rows_kernel<FC_ACT_GELU, 0>); break;
+            case FC_ACT_RELU: k5 ? go(premlp_rows_kernel<FC_ACT_RELU, 5>) : go(premlp_rows_kernel<FC_ACT_RELU, 0>); break;
+            case FC_ACT_ELU: k5 ? go(premlp_rows_kernel<FC_ACT_ELU, 5>) : go(premlp_rows_kernel<FC_ACT_ELU, 0>); break;
+            case FC_ACT_LRELU02: k5 ? go(premlp_rows_kernel<FC_ACT_LRELU02, 5>) : go(premlp_rows_kernel<FC_ACT_LRELU02, 0>); break;
+            default: k5 ? go(premlp_rows_kernel<FC_ACT_NONE, 5>) : go(premlp_rows_kernel<FC_ACT_NONE, 0>); break;
         }
         return;
     }
