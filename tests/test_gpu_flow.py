@@ -276,6 +276,33 @@ def test_persistent_spline_gemm_walks_several_tiles_per_workgroup():
         assert torch.isfinite(ref).all()
 
 
+@pytest.mark.parametrize("latent_dim, act", [(200, "GELU"), (300, "RELU"), (264, "ELU")])
+def test_row_resident_pre_attention_kernel_other_widths_and_activations(latent_dim, act):
+    """The shipped pre-attention chain kernel (activations in registers, csrc/premlp.hip) away from the C2 shape it is specialised for:
+    x1 widths 100 / 150 / 132 columns (k padded to 128 / 160 / 160: the in_layer's k steps read at run time or compile time, weight
+    rows of 32 / 40 sixteen-byte chunks with their two swizzle masks and piece-to-row maps) and the three activations the reference
+    accepts, against the separate GEMM launches."""
+    from flowcompare_amd import engine
+    lib = engine.lib()
+    cfg = fa.named_config("c2_dgcnn_attn_spline", n_flow_layers=3, sample_size=300, latent_dim=latent_dim, coupling_block_nonlinearity=act)
+    torch.manual_seed(31)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    g = torch.Generator().manual_seed(32)
+    B, N, M = 2, 300, 310
+    e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
+    eps = [torch.randn(*sh, generator=g).to(DEV) for sh in md["flow"].noise_shapes(B, N)]      # (a CIF block per layer when cif_latent_dim > latent_dim)
+    batch = (e0.to(DEV), e1.to(DEV), None)
+    try:
+        _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+        lib.fc_debug_set(8, 0)
+        _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+    finally:
+        lib.fc_debug_set(8, 2)
+    err = (lp - ref).abs().max().item()
+    print(f"latent {latent_dim}, {act}: max |row-resident - separate launches| {err:.2e}")
+    assert torch.isfinite(lp).all() and err < 5e-4
+
+
 def test_c2_layer_widths_with_ragged_sizes_match_the_oracle():
     """The shipped C2 fast paths (fused spline epilogue with its limb chain, LayerNorm -> q fold, K|V limb images, split-fp16
     attention) at the real layer widths but ragged sizes: rows not a multiple of any tile (3 x 333 targets), 77 context points
