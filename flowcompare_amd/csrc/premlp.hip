@@ -268,13 +268,17 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void pr_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void pr_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
 
-// DMA of chunk c (weight rows 32 c .. 32 c + 31, all K) of layer L into `dst`: 1 KiB pieces dealt round-robin to the eight waves
-__device__ __forceinline__ void pr_dma(const PreMlpLayer& L, int c, char* dst, int wave, int lane) {
+// DMA of chunk c (weight rows 32 c .. 32 c + 31, all K) of layer L into `dst`: 1 KiB pieces dealt round-robin to FOUR of the eight waves --
+// waves 0..3 for even chunks of the stream, 4..7 for odd ones.  Waves w and w + 4 share a SIMD, and issuing a piece stalls its wave
+// ~190 cycles: with all eight issuing behind the barrier every SIMD stood for 4 x 190 cycles per chunk; now one wave per SIMD issues
+// (8 pieces) while its partner is already multiplying.
+__device__ __forceinline__ void pr_dma(const PreMlpLayer& L, int c, char* dst, int wave, int lane, int grp) {
+    if ((wave >> 2) != grp) return;
     const int cpr = L.K_pad >> 2;                            // 16-byte chunks per weight row (64 at K = 256, 40 at K = 160)
     const int sw = (cpr & 15) == 0 ? 15 : 7;
     const int npieces = cpr >> 1;                            // 32 rows * cpr chunks / 64 lanes
     const char* base = reinterpret_cast<const char*>(L.W2) + (size_t)c * PR_CH * cpr * 16;
-    for (int pc = wave; pc < npieces; pc += 8) {
+    for (int pc = wave & 3; pc < npieces; pc += 4) {
         const int ci = pc * 64 + lane;
         const int r = cpr == 64 ? ci >> 6 : ci / cpr;
         const int q = ci - r * cpr;
@@ -308,7 +312,8 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
         for (int l = 0; l < 5; ++l) biasbuf[l * PM_H + tid] = (Ls[l]->bias && (l < 4 || tid < 64)) ? Ls[l]->bias[tid] : 0.f;
     }
-    pr_dma(p.in, 0, smc, wave, lane);
+    pr_dma(p.in, 0, smc, wave, lane, 0);
+    int grp = 1;                                             // which half of the waves issues the next chunk's pieces
 
     f16x8 ah[8], al[8], nh[8], nl[8];
     // the residual of the second hidden layer (= the in_layer's output) is parked in global scratch while hidden layer 0 runs -- 64 registers
@@ -351,7 +356,8 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             for (int i = 0; i < 4; ++i) { am[mb][i] = 0.f; ac[mb][i] = 0.f; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // own pieces of this chunk have landed
         __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
-        if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PR_BUF, wave, lane);
+        if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PR_BUF, wave, lane, grp);
+        grp ^= 1;
         after_dma();                                                    // (loads that must not sit in front of the wait above: they get this chunk's time to land)
         const int cpr = L.K_pad >> 2, KS = L.K_pad >> 5;
         const int sw = (cpr & 15) == 0 ? n : (n & 7);
