@@ -381,14 +381,18 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     };
     // accumulator order (block mb, register i = feature 16 mb + 4 kg + i) -> operand order: t[e] = out-feature 32 c + 8 kg + e (before bias)
     auto fold = [&](const floatx4 (&am)[2], const floatx4 (&ac)[2], float (&t)[8]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float P = am[0][i] + ac[0][i] * (1.0f / 2048.0f), Q = am[1][i] + ac[1][i] * (1.0f / 2048.0f);
-            pr_swap32(P, Q);
-            pr_swap16(P, Q);
-            t[i] = P;
-            t[4 + i] = Q;
-        }
+        float P0 = am[0][0] + ac[0][0] * (1.0f / 2048.0f), P1 = am[0][1] + ac[0][1] * (1.0f / 2048.0f);
+        float P2 = am[0][2] + ac[0][2] * (1.0f / 2048.0f), P3 = am[0][3] + ac[0][3] * (1.0f / 2048.0f);
+        float Q0 = am[1][0] + ac[1][0] * (1.0f / 2048.0f), Q1 = am[1][1] + ac[1][1] * (1.0f / 2048.0f);
+        float Q2 = am[1][2] + ac[1][2] * (1.0f / 2048.0f), Q3 = am[1][3] + ac[1][3] * (1.0f / 2048.0f);
+        // the eight lane swaps as one block: two wait states between a VALU write and the first swap that reads it; a pair's
+        // permlane16 swap stands three instructions behind its permlane32 swap
+        asm volatile("s_nop 1\n\t"
+                     "v_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+                     "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\t"
+                     "s_nop 1"
+                     : "+v"(P0), "+v"(P1), "+v"(P2), "+v"(P3), "+v"(Q0), "+v"(Q1), "+v"(Q2), "+v"(Q3));
+        t[0] = P0; t[1] = P1; t[2] = P2; t[3] = P3; t[4] = Q0; t[5] = Q1; t[6] = Q2; t[7] = Q3;
     };
     // bias, residual, activation, limb split of one chunk, pushed into the output FIFO nh / nl (slot 7 after a shift by one: every
     // chunk then runs the SAME code, so a layer is a loop of ~4 KB instead of 30 KB of straight-line code -- unrolled, the kernel
