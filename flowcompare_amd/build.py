@@ -17,9 +17,14 @@ LIB = os.path.join(HERE, "libfcflow.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
-# per-file additions.  premlp.hip: hipcc packs adjacent scalar f32 adds / muls of the epilogue into v_pk_add_f32 / v_pk_mul_f32, which cost more issue
-# time beside MFMAs than the scalar forms they replace (MI355X_MICROARCH.md, "packed f32 VALU")
-EXTRA_FLAGS = {"premlp.hip": ["-fno-slp-vectorize"]}
+# per-file additions.  premlp.hip: hipcc packs adjacent scalar f32 adds / muls of the epilogue into v_pk_add_f32 / v_pk_mul_f32 (the guide lists
+# packed f32 VALU beside MFMAs as an anti-lever; measured here: no difference).  attention.hip: the same packing in the softmax: -1.9 % kernel time
+# without it (28.2 -> 27.7 ms per C2 step, same box); gemm.hip is 1 % FASTER with the packing and keeps it.  Developer option for same-box A/B runs:
+# FC_EXTRA_FLAGS="attention.hip:-fno-slp-vectorize;gemm.hip:-fno-slp-vectorize" adds flags to single files.
+EXTRA_FLAGS = {"premlp.hip": ["-fno-slp-vectorize"], "attention.hip": ["-fno-slp-vectorize"]}
+for _kv in os.environ.get("FC_EXTRA_FLAGS", "").split(";"):
+    if ":" in _kv:
+        EXTRA_FLAGS.setdefault(_kv.split(":", 1)[0], []).extend(_kv.split(":", 1)[1].split(","))
 
 
 def _sources():
