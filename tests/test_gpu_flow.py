@@ -324,6 +324,36 @@ def test_c2_layer_widths_with_ragged_sizes_match_the_oracle():
     assert lp.shape == (B, N) and abs(float(bpd) - float(bpd_o)) < BPD_TOL and d.max() < PER_POINT_TOL
 
 
+@pytest.mark.parametrize("bins", [4, 16])
+def test_spline_bin_counts_other_than_eight_match_the_oracle(bins):
+    """num_bins_spline 4 and 16 (models/spline_coupling.py:69-169): 13 / 49 parameters per transformed dim, 9 / 2 dims per 128-column tile in
+    the dim-major column order (only K = 8 uses the register-slot order and the transposed kernels), evaluated in the GEMM epilogue
+    through the LDS parameter tile and, with knob 7 = 0, by the stand-alone spline kernel -- both against the fp64 oracle."""
+    from flowcompare_amd import engine
+    lib = engine.lib()
+    cfg = fa.named_config("c2_dgcnn_attn_spline", n_flow_layers=2, sample_size=200, num_bins_spline=bins)
+    torch.manual_seed(41)
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    g = torch.Generator().manual_seed(42)
+    B, N, M = 2, 200, 150
+    e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
+    eps = [torch.randn(B, N, 294, generator=g)]
+    batch = (e0.to(DEV), e1.to(DEV), None)
+    sd_f = {k: v.cpu().double() for k, v in md["flow"].state_dict().items()}
+    sd_e = {k: v.cpu().double() for k, v in md["input_embedder"].state_dict().items()}
+    with torch.no_grad():
+        _, lp_o, bpd_o = O.inner_loop(cfg, sd_f, sd_e, (e0.double(), e1.double(), None), [e.double() for e in eps])
+    try:
+        for fused in (1, 0):
+            lib.fc_debug_set(7, fused)
+            _, lp, bpd = fa.inner_loop(batch, md, cfg, eps=[e.to(DEV) for e in eps])
+            d = (lp.cpu().double() - lp_o).abs()
+            print(f"{bins} bins, fused spline {fused}: max {d.max():.2e} bpd diff {abs(float(bpd) - float(bpd_o)):.2e}")
+            assert abs(float(bpd) - float(bpd_o)) < BPD_TOL and d.max() < PER_POINT_TOL
+    finally:
+        lib.fc_debug_set(7, 1)
+
+
 def test_cif_stack_at_real_layer_widths_matches_the_oracle():
     """CIFblock (augment -> conditional affine -> slice around the attention-conditioned coupling, models/cif_block.py:49-112) at the
     real layer widths (latent 300, CIF latent 364): the pair-packed epilogues on the eight-wave tile with slot-buffered log-dets,
