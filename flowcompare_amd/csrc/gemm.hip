@@ -253,9 +253,11 @@ void gemm_f32_kernel(const GemmParams p) {
         // point (the other 64 sit in lane ^ 32).  With the column order of spline.h that is every parameter of 2-3 transformed dims in
         // registers with compile-time indices: the spline is evaluated straight from the accumulators, the tile never goes through LDS
         // (no 66 KB parameter tile, no transposition, no epilogue barrier).
-        static_assert(BN == 128 && ((VAR == 8 && BM == 256 && WM == 4 && WN == 2) || (VAR == 9 && BM == 128 && WM == 2 && WN == 2) ||
-                                    (VAR == 10 && BM == 128 && WM == 4 && WN == 1 && EPI == EPI_SPLINE)),
-                      "LDS-DMA loop: 256x128 on 4x2 waves (VAR 8), 128x128 on 2x2 waves (VAR 9) or on 4x1 waves, transposed (VAR 10)");
+        static_assert((BN == 128 && ((VAR == 8 && BM == 256 && WM == 4 && WN == 2) || (VAR == 9 && BM == 128 && WM == 2 && WN == 2) ||
+                                     (VAR == 10 && BM == 128 && WM == 4 && WN == 1 && EPI == EPI_SPLINE))) ||
+                          (VAR == 9 && BM == 64 && BN == 64 && WM == 2 && ((WN == 2 && EPI == EPI_LINEAR) || (WN == 1 && EPI == EPI_AFFINE))),
+                      "LDS-DMA loop: 256x128 on 4x2 waves (VAR 8), 128x128 on 2x2 waves (VAR 9) or on 4x1 waves, transposed (VAR 10); 64x64 on 2x2 "
+                      "waves (EPI_LINEAR) / 2x1 waves (EPI_AFFINE: a wave's 64 columns are one pair block) for launches too small to fill the chip with 128x128 tiles");
         constexpr int NST8 = VAR == 8 ? 3 : 2;
         constexpr int ROWB8 = 128, STAGE8 = (BM + BN) * ROWB8;        // launch_cfg reserves NST8 * STAGE8
         constexpr int PPW = STAGE8 / 1024 / (NT / 64);                       // 1-KB DMA pieces per wave and stage: 6
@@ -1180,6 +1182,7 @@ size_t gemm_read_stamps(unsigned long long* host, size_t max_n) {
 int g_spline_prefetch = 0;   // knob 21: persistent fused spline GEMM (VAR 11): 1 = a tile's k loop starts at a column-tile dependent step and wraps around (measured: no gain, other summation order); 0 = every tile starts at k = 0 (shipped, bit-identical to VAR 7-10)
 int g_gemm_dma = 4;          // knob 13: fused spline GEMM: 4 = persistent transposed LDS-DMA loop, splines evaluated from the accumulator registers (VAR 11, shipped; K = 8 bins), 3 = the same, one tile per workgroup (VAR 10), 2 = LDS-DMA loop on the 128x128 four-wave tile with the LDS parameter tile (VAR 9), 1 = on the 256x128 tile (VAR 8), 0 = register-staged (VAR 7); bit-identical results
 int g_spline_ablate = 0;     // knob 14: diagnostics, results invalid (1 = no spline evaluation, 2 = main loop only, 3 = no parameter-tile write, 4 = no x2 store, 5 = stop behind the tile write)
+int g_gemm_small_tiles = 1;  // knob 22: limb-chained Linear launches with at most 256 tiles of 128x128 run on 64x64 tiles
 int g_gemm_dma_linear = 2;   // knob 15: limb-image A in a Linear layer: 2 = LDS-DMA loop on the 128x128 four-wave tile (shipped), 1 = on the 256x128 tile, 0 = register-staged
 int g_limb_chain_all = 1;    // knob 16: every hidden activation of the coupling MLP exists only as a limb image (A16 / residual16 / C16)
 int g_gemm_prefetch3 = 0;    // knob 17: three register sets of prefetch in the Linear loop (VAR 6): bit-identical, measured 3.5 % slower
@@ -1292,7 +1295,13 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             // A arrives as the limb image of the producing layer (limb-chained MLP): the copy-only main loops
             if (!(f16 && g_gemm_bigtile == 3 && L.nseg == 1 && L.N_pad > 64 && L.n_alloc >= round_up(L.N_pad, 128)))
                 throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: a limb-image A operand needs the split-fp16 loop, one segment and N > 64");
-            if (g_gemm_dma_linear == 2) { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 2, 2, EPI_LINEAR, 9>(p, s); }
+            if (g_gemm_dma_linear == 2 && g_gemm_small_tiles && (rows_alloc / 128) * ((L.N_pad + 127) / 128) <= 256 && L.N_pad % 64 == 0) {
+                // fewer 128x128 tiles than workgroup slots (C1: 2 x 1024 points = 16 row tiles): four times as many 64x64 tiles, each a
+                // quarter of the MFMA work per k step -- the launch is bound by one workgroup's k loop, not by throughput
+                p.nbm = rows_alloc / 64;
+                launch_cfg<64, 64, 2, 2, EPI_LINEAR, 9>(p, s);
+            }
+            else if (g_gemm_dma_linear == 2) { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 2, 2, EPI_LINEAR, 9>(p, s); }
             else if (g_gemm_dma_linear && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 8>(p, s); }
             else { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 4, 2, EPI_LINEAR, 7>(p, s); }
         } else if (L.N_pad <= 64) {
@@ -1361,7 +1370,8 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: a limb-image A operand in a pair-packed epilogue exists for the forward affine coupling only");
         if (f16 && e.ldj_part && !e.inverse && g_gemm_bigtile == 3) {
             if (e.ldj_pitch < (size_t)rows_alloc) throw Error(FC_ERR_INVALID, "launch_gemm: log-det slot pitch smaller than the row count");
-            if (e.A16) launch_cfg<128, 128, 2, 2, EPI_AFFINE, 9>(p, s);            // limb-chained MLP: copy-only LDS-DMA loop (a wave's 64 columns = one pair block)
+            if (e.A16 && g_gemm_small_tiles && (rows_alloc / 128) * ((L.N_pad + 127) / 128) <= 256) { p.nbm = rows_alloc / 64; launch_cfg<64, 64, 2, 1, EPI_AFFINE, 9>(p, s); }   // (small launch: 64x64 tiles, see EPI_LINEAR)
+            else if (e.A16) launch_cfg<128, 128, 2, 2, EPI_AFFINE, 9>(p, s);       // limb-chained MLP: copy-only LDS-DMA loop (a wave's 64 columns = one pair block)
             else if (epi_kind == EPI_AFFINE) launch_cfg<128, 128, 4, 2, EPI_AFFINE, 5>(p, s);
             else if (epi_kind == EPI_AUGMENT) launch_cfg<128, 128, 4, 2, EPI_AUGMENT, 5>(p, s);
             else launch_cfg<128, 128, 4, 2, EPI_SLICE, 5>(p, s);

@@ -208,7 +208,7 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
     eps = [torch.randn(B, N, 294, generator=g).to(DEV)]
     batch = (e0.to(DEV), e1.to(DEV), None)
-    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 2, 9: 1, 10: 1, 13: 4, 15: 2, 16: 1, 17: 0, 19: 0, 21: 0}
+    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 2, 9: 1, 10: 1, 13: 4, 15: 2, 16: 1, 17: 0, 19: 0, 21: 0, 22: 1}
     try:
         _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
         for name, knobs in (("unfused spline", {7: 0}), ("LDS-tile pre-attention chain kernel", {8: 1}), ("separate pre-attention GEMM launches + LayerNorm -> q fold", {8: 0}), ("separate LayerNorm + q projection", {8: 0, 10: 0}), ("no limb chain", {9: 0}), ("limb chain into the spline GEMM only", {16: 0}), ("limb-chained pre-attention MLP", {8: 0, 19: 1}), ("limb-chained hidden layers on the register-staged tile", {15: 0}), ("limb-chained hidden layers on the 256x128 DMA tile", {15: 1}), ("fp32-input attention", {5: 0}),
@@ -237,6 +237,10 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
         err = (lp - ref).abs().max().item()
         print(f"persistent fused spline GEMM with rotated k loops: max |log-prob - default path| {err:.2e}")
         assert err < 5e-4
+        lib.fc_debug_set(22, 0)                                   # 128x128 tiles also for launches with few tiles (this test: 5 row tiles -> 64x64 tiles by default)
+        _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+        lib.fc_debug_set(22, 1)
+        assert torch.equal(lp, ref), "64x64 tiles for small launches changed the limb-chained GEMMs' results"
         lib.fc_debug_set(17, 1)                                   # three register sets of prefetch instead of two: same MFMAs, same order
         _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
         lib.fc_debug_set(17, 0)
