@@ -1304,7 +1304,8 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             else if (g_gemm_dma_linear == 2) { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 2, 2, EPI_LINEAR, 9>(p, s); }
             else if (g_gemm_dma_linear && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 8>(p, s); }
             else { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 4, 2, EPI_LINEAR, 7>(p, s); }
-        } else if (L.N_pad <= 64) {
+        } else if (L.N_pad <= 64 || (f16 && g_gemm_small_tiles && !e.C16 && (rows_alloc / 128) * ((L.N_pad + 127) / 128) <= 128 && L.n_alloc >= round_up(L.N_pad, 64))) {
+            // (64-wide layers; and fp32-A launches with at most 128 tiles of 128x128: twice as many 128x64 tiles)
             p.nbm = rows_alloc / 128;
             if (f16) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 5>(p, s);
             else if (split) launch_cfg<128, 64, 4, 1, EPI_LINEAR, 3>(p, s);
