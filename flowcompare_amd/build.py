@@ -21,7 +21,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 # packed f32 VALU beside MFMAs as an anti-lever; measured here: no difference).  attention.hip: the same packing in the softmax: -1.9 % kernel time
 # without it (28.2 -> 27.7 ms per C2 step, same box); gemm.hip is 1 % FASTER with the packing and keeps it.  Developer option for same-box A/B runs:
 # FC_EXTRA_FLAGS="attention.hip:-fno-slp-vectorize;gemm.hip:-fno-slp-vectorize" adds flags to single files.
-EXTRA_FLAGS = {"premlp.hip": ["-fno-slp-vectorize"], "attention.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"premlp.hip": ["-fno-slp-vectorize"], "attention.hip": ["-fno-slp-vectorize"],
+               # mlprows.hip: the epilogue is hand-placed in micro-steps behind single MFMAs; SLP packing merges steps of different slots
+               "mlprows.hip": ["-fno-slp-vectorize"]}
 for _kv in os.environ.get("FC_EXTRA_FLAGS", "").split(";"):
     if ":" in _kv:
         EXTRA_FLAGS.setdefault(_kv.split(":", 1)[0], []).extend(_kv.split(":", 1)[1].split(","))

@@ -8,6 +8,7 @@
 #include <map>
 #include <stdexcept>
 #include <mutex>
+#include <functional>
 
 #include "../../include/fcflow.h"
 
@@ -97,6 +98,8 @@ struct PackedLinear {
                                    // does not fit fp16): operand of the default split-fp16 GEMM loop
     unsigned short* W3 = nullptr;  // the same matrix as 3 bf16 limbs, [N_alloc][K_pad/16][3][16]: x = hi + mid + lo exactly to 24 bits
                                    // (operand image of the split-bf16 GEMM variant, see gemm.hip)
+    unsigned short* Wf = nullptr;  // K <= 512 -> 512 layers of a coupling MLP: the fp16 limb image pre-tiled in MFMA-fragment order,
+                                   // [N/32][ks][2][64 lanes][8] (mlprows.hip: one LDS-DMA piece = one linear 1 KiB read); null otherwise
     int N_pad = 0;             // columns written (multiple of 32)
     int K_pad = 0;             // multiple of 32 (sum of segment widths)
     int seg_k[3] = {0, 0, 0};  // padded K of each A segment
@@ -169,8 +172,18 @@ struct Fp16Guard {
     Fp16Guard(int* dev_flag, hipStream_t s);
     ~Fp16Guard();
     bool overflowed();            // closes the scope: waits for the stream and reads the flag
+    void defer(std::function<void()> rerun);   // closes the scope WITHOUT waiting: the flag is copied to pinned host memory behind the pass and
+                                               // the pass is queued for fc_range_check_resolve (deferred range check, below)
     int* flag; hipStream_t stream; bool open;
 };
+// Deferred range check (fc_range_check_defer / _resolve, include/fcflow.h): with the calling thread's switch on, a guarded entry point only
+// ENQUEUES its fast pass, a 4-byte copy of the flag into a pinned host slot and an event -- no stream synchronisation, so any number of
+// forwards can be queued back to back.  guard_resolve() then walks the queued passes in order: it waits for a pass's event, and repeats the
+// pass on the unbounded-range loops if its flag came back set (or if an earlier pass was repeated: it may have consumed that pass's output).
+bool guard_deferred();
+int guard_pending();
+void guard_set_deferred(bool on);
+int guard_resolve();              // returns the number of passes it repeated
 // Training primitives (train.hip): the CALLER owns the overflow flag for a whole optimisation step (forward and backward run on
 // different host threads under torch.autograd), so the scope only lends it to launch_gemm for one call -- no reset, no wait.
 struct Fp16FlagScope {
@@ -186,8 +199,14 @@ void launch_lnq_finalize(float* q, int ldq, const float* sumsq, int nslots, size
 bool gemm_split_enabled();        // a split (limb) GEMM loop is the active variant: the fused spline epilogue is available
 int* gemm_fp16_flag();         // the open scope's device flag of the calling thread, or null
 template <class F>
-inline void run_fp16_guarded(int* dev_flag, hipStream_t s, F&& fn) {
+inline void run_fp16_guarded(int* dev_flag, hipStream_t s, F&& fn, bool deferrable = false) {
     if (!dev_flag || !gemm_fp16_enabled()) { fn(); return; }
+    if (deferrable && guard_deferred()) {           // (fn must own its arguments: it may run again after this call has returned)
+        Fp16Guard g(dev_flag, s);
+        fn();
+        g.defer(std::function<void()>(fn));
+        return;
+    }
     bool over;
     { Fp16Guard g(dev_flag, s); fn(); over = g.overflowed(); }
     if (over) fn();
@@ -208,6 +227,13 @@ bool premlp_fusable(const PackedLinear& in, const std::vector<PackedLinear>& mid
 void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::vector<PackedLinear>& mid, const PackedLinear& out,
                    const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s, float* keep_ws = nullptr,
                    size_t keep_floats = 0);
+// mlprows.hip: in_layer + hidden layers of a 512-wide coupling MLP in one launch, activations resident in registers
+size_t mlp_rows_image_bytes(int K_pad);
+void launch_mlp_rows_image(const PackedLinear& L, unsigned short* Wf, hipStream_t s);      // fills L's fragment-major image from L.W2
+bool mlp_rows_eligible(const PackedLinear& in, const std::vector<PackedLinear>& mid, int act);
+void launch_mlp_rows(const PackedLinear& in, const std::vector<PackedLinear>& mid, const ASeg* segs, const float* rowscal, int act,
+                     float* const h[3], unsigned short* out16, int rows_alloc, int rows_valid, hipStream_t s);
+void launch_limb_decode(const unsigned short* img, float* out, int ldo, int rows, int width, hipStream_t s);   // row-major limb image -> fp32 (tests)
 // staging.hip: the steps either side of the path
 void launch_fps_nd(const float* pts, int ld, int C, int64_t* idx, int B, int n, int m, float* dist_scratch, hipStream_t s);
 void launch_co_unit_sphere(const float* p0, int n0, const float* p1, int n1, int ld, float* o0, float* o1, float* inverse, int B, hipStream_t s);

@@ -185,9 +185,9 @@ int fc_dgcnn_embed_f32(fc_dgcnn* emb, const float* pts, float* out, int32_t B, i
     FC_API_BEGIN
     if (!emb || !workspace) throw fc::Error(FC_ERR_INVALID, "fc_dgcnn_embed_f32: null handle / workspace");
     // fast split-fp16 GEMMs first; the whole pass is repeated with the bf16-limb GEMMs if an activation left fp16's range
-    fc::run_fp16_guarded(emb->fp16_flag, (hipStream_t)stream, [&] {
+    fc::run_fp16_guarded(emb->fp16_flag, (hipStream_t)stream, [=] {
         fc::dgcnn_forward(*emb, pts, out, B, M, workspace, workspace_bytes, (hipStream_t)stream);
-    });
+    }, true);
     FC_API_END
 }
 

@@ -458,6 +458,7 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
         pack_mlp_mid(f.arena, wt, pn, b.net);
         b.net.in_layer = build_in_layer(f, wt, pn, d.d1, d.d1_pad, b.has_attn ? &b.attn : nullptr);
         build_out_layer(f, wt, pn, b.net);
+        attach_mlp_rows_images(f.arena, b.net);
         h_pad = std::max(h_pad, max_hidden_pad(b.net));
         if (c.flow_type != FC_FLOW_AFFINE) ldp = b.net.out_layer.N_pad;
         if (c.flow_type == FC_FLOW_EXPONENTIAL) {
@@ -562,6 +563,12 @@ int g_premlp_chain = 0;      // knob 19: limb chain through the pre-attention ML
                              // output tile, the tile-boundary cost of the DMA loop outweighs its main loop: measured 1 % slower end to end)
 static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_segs, const float* rowscal, FlowWs& w, int act, hipStream_t s,
                           unsigned short* last_limbs = nullptr) {
+    // 512-wide coupling nets inside a guard scope: in_layer + hidden layers as ONE row-resident launch (mlprows.hip); the scratch images
+    // of its intermediate activations live in the h[] buffers (same 2 KB per row as a 512-wide fp32 panel)
+    if (last_limbs && f.d.H_pad == 512 && gemm_limb_chain_all_ok() && mlp_rows_eligible(m.in_layer, m.mid, act)) {
+        launch_mlp_rows(m.in_layer, m.mid, in_segs, rowscal, act, w.h, last_limbs, w.P_pad, w.P, s);
+        return -1;
+    }
     return run_mlp_hidden_generic(m, in_segs, rowscal, act, w.h, std::max(f.d.H_pad, 32), w.P_pad, s, w.P, last_limbs);
 }
 
@@ -887,9 +894,11 @@ int fc_flow_logprob_f32(fc_flow* flow, const float* x, const float* ctx, const f
     FC_API_BEGIN
     if (!flow || !workspace) throw fc::Error(FC_ERR_INVALID, "fc_flow_logprob_f32: null flow / workspace");
     // fast split-fp16 GEMMs first; the whole pass is repeated with the bf16-limb GEMMs if an activation left fp16's range
-    fc::run_fp16_guarded(flow->fp16_flag, (hipStream_t)stream, [&] {
-        fc::flow_forward(*flow, x, ctx, extra, eps, n_eps, logprob, z_out, B, N, M, workspace, workspace_bytes, (hipStream_t)stream);
-    });
+    // (deferred range check, fc_range_check_defer: the pass may be repeated after this call has returned -- it owns its arguments)
+    const std::vector<const float*> eps_own(eps, eps + (eps && n_eps > 0 ? n_eps : 0));
+    fc::run_fp16_guarded(flow->fp16_flag, (hipStream_t)stream, [=] {
+        fc::flow_forward(*flow, x, ctx, extra, eps_own.data(), n_eps, logprob, z_out, B, N, M, workspace, workspace_bytes, (hipStream_t)stream);
+    }, true);
     FC_API_END
 }
 

@@ -1214,6 +1214,64 @@ bool Fp16Guard::overflowed() {
     return h != 0;
 }
 
+// ---- deferred range check (common.h).  Per thread: the switch, the queued passes and a pool of pinned flag slots / events.
+namespace {
+struct DeferredPass { std::function<void()> rerun; int* dev_flag; hipStream_t stream; int* host_flag; hipEvent_t ev; };
+struct DeferState {
+    bool on = false;
+    std::vector<DeferredPass> pending;
+    std::vector<std::pair<int*, hipEvent_t>> pool;
+    ~DeferState() {
+        for (auto& pe : pool) { (void)hipHostFree(pe.first); (void)hipEventDestroy(pe.second); }
+        for (auto& d : pending) { (void)hipHostFree(d.host_flag); (void)hipEventDestroy(d.ev); }
+    }
+};
+thread_local DeferState t_defer;
+}  // namespace
+bool guard_deferred() { return t_defer.on; }
+int guard_pending() { return (int)t_defer.pending.size(); }
+void guard_set_deferred(bool on) { t_defer.on = on; }
+void Fp16Guard::defer(std::function<void()> rerun) {
+    t_fp16_flag = nullptr;
+    open = false;
+    DeferredPass d{std::move(rerun), flag, stream, nullptr, nullptr};
+    if (!t_defer.pool.empty()) { d.host_flag = t_defer.pool.back().first; d.ev = t_defer.pool.back().second; t_defer.pool.pop_back(); }
+    else {
+        FC_HIP(hipHostMalloc((void**)&d.host_flag, sizeof(int), hipHostMallocDefault));
+        FC_HIP(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
+    }
+    *d.host_flag = 0;
+    FC_HIP(hipMemcpyAsync(d.host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    FC_HIP(hipEventRecord(d.ev, stream));
+    t_defer.pending.push_back(std::move(d));
+}
+int guard_resolve() {
+    int repeated = 0;
+    std::vector<DeferredPass> todo;
+    todo.swap(t_defer.pending);
+    std::exception_ptr err;
+    for (DeferredPass& d : todo) {
+        try {
+            if (!err) {
+                FC_HIP(hipEventSynchronize(d.ev));
+                if (*d.host_flag) {                          // the fast pass left fp16's range: the whole pass again on the bf16-limb loops
+                    g_fp16_fallbacks.fetch_add(1);
+                    d.rerun();
+                    ++repeated;
+                } else if (repeated) {                       // an earlier pass was repeated and may feed this one: fast pass again, checked at once
+                    bool over;
+                    { Fp16Guard g(d.dev_flag, d.stream); d.rerun(); over = g.overflowed(); }
+                    if (over) d.rerun();
+                    ++repeated;
+                }
+            }
+        } catch (...) { err = std::current_exception(); }
+        t_defer.pool.emplace_back(d.host_flag, d.ev);
+    }
+    if (err) std::rethrow_exception(err);
+    return repeated;
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
     constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : VAR == 11 ? 2 * (size_t)(BM + BN) * 128 + 1024 : (VAR == 9 || VAR == 10) ? 2 * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 6 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);

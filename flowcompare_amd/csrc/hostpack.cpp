@@ -420,6 +420,17 @@ int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float*
     }
     return last_limbs ? -1 : cur;
 }
+void attach_mlp_rows_images(DeviceArena& arena, PackedMLP& m) {
+    auto fits = [](const PackedLinear& L) { return L.W2 && L.N_pad == 512 && L.K_pad <= 512 && L.K_pad % 16 == 0 && L.n_alloc >= 512 && L.bias; };
+    if (m.mid.empty() || !fits(m.in_layer)) return;
+    for (const PackedLinear& L : m.mid) if (!fits(L) || L.K_pad != 512 || L.nseg != 1) return;
+    auto attach = [&](PackedLinear& L) {
+        L.Wf = (unsigned short*)arena.alloc_bytes(mlp_rows_image_bytes(L.K_pad));
+        launch_mlp_rows_image(L, L.Wf, nullptr);
+    };
+    attach(m.in_layer);
+    for (PackedLinear& L : m.mid) attach(L);
+}
 int max_hidden_pad(const PackedMLP& m) {
     int mx = 0;
     for (int s : m.sizes) mx = std::max(mx, round_up(s, 32));

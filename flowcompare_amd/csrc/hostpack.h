@@ -48,6 +48,9 @@ struct PackedMLP {
 // packs layers.{i} of `prefix` (plain [round32(prev)] -> [round32(next)]) and returns hidden sizes; in/out are left to the caller
 void pack_mlp_mid(DeviceArena& arena, const WeightTable& wt, const std::string& prefix, PackedMLP& out);
 int max_hidden_pad(const PackedMLP& m);
+// Row-resident coupling MLP (mlprows.hip): gives the K <= 512 -> 512 -> ... -> 512 layers of a coupling net their second fp16 limb image in
+// MFMA-fragment order (PackedLinear::Wf), built on the device from W2; a net of any other shape is left as it is.
+void attach_mlp_rows_images(DeviceArena& arena, PackedMLP& m);
 
 // Runs in_layer + hidden layers of one reference MLP (models/nets.py:19-30: act(in); even hidden layer i: keep = x, x = act(W x);
 // odd: x = act(keep + W x)) over three rotating activation buffers h[0..2] of pitch ldh; returns the buffer index holding the

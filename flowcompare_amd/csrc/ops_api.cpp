@@ -17,7 +17,7 @@ struct TmpBuf {
 }  // namespace fc
 
 
-namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; size_t gemm_read_stamps(unsigned long long*, size_t); }
+namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; size_t gemm_read_stamps(unsigned long long*, size_t); }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }
 
 extern "C" {
@@ -41,6 +41,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 19) fc::g_premlp_chain = value;
     else if (key == 21) fc::g_spline_prefetch = value;
     else if (key == 22) fc::g_gemm_small_tiles = value;
+    else if (key == 23) fc::g_mlp_rows = value;          /* 1 = row-resident coupling MLP chain (mlprows.hip, default), 0 = one GEMM launch per layer */
     else if (key == 20) fc::g_gemm_stamp = value;        /* diagnostic: in-kernel phase stamps of the LDS-DMA fused-spline launches */
     else if (key == 14) fc::g_spline_ablate = value;     /* diagnostic: 1 = fused spline epilogue without the spline evaluation, 2 = main loop only (results invalid) */
     else return FC_ERR_INVALID;
@@ -56,6 +57,21 @@ int32_t fc_debug_spline_tile_pos(int32_t c, int32_t K) { return fc::spline_tile_
 int64_t fc_debug_gemm_stamps(uint64_t* host, int64_t max_n) {
     try { return (int64_t)fc::gemm_read_stamps(reinterpret_cast<unsigned long long*>(host), (size_t)max_n); } catch (...) { return -1; }
 }
+
+/* deferred range check (include/fcflow.h) */
+int fc_range_check_defer(int32_t on) {
+    FC_API_BEGIN
+    if (!on && fc::guard_pending()) fc::guard_resolve();
+    fc::guard_set_deferred(on != 0);
+    FC_API_END
+}
+int fc_range_check_resolve(int32_t* n_repeated) {
+    FC_API_BEGIN
+    const int n = fc::guard_resolve();
+    if (n_repeated) *n_repeated = n;
+    FC_API_END
+}
+int32_t fc_range_check_pending(void) { return fc::guard_pending(); }
 
 /* number of calls that were repeated with the bf16-limb GEMMs because an activation left fp16's range (tests, diagnostics) */
 int64_t fc_debug_fp16_fallbacks(void) { return (int64_t)fc::gemm_fp16_fallbacks(); }
@@ -105,6 +121,56 @@ int fc_op_linear_f32(const float* x, const float* W, const float* bias, const fl
     ASeg a{xp.f(), kp};
     run_fp16_guarded((int*)flag.p, s, [&] { launch_gemm(L, &a, rp, e, EPI_LINEAR, s); });
     launch_pack_rows(cp.f(), np, N, y, N, 0, N, rows, s);
+    FC_HIP(hipStreamSynchronize(s));
+    FC_API_END
+}
+
+/* in_layer + hidden layers of one reference MLP (models/nets.py:19-30) at hidden width 512 over cat(x0, x1) (+ the rank-1 extra-context
+   term rowscal[row] * net.colvec): the last hidden activation, decoded from the limb image the output GEMM would consume.  use_rows != 0:
+   the row-resident chain kernel (mlprows.hip); 0: one GEMM launch per layer (limb-chained).  Tensors (host fp32): net.in_layer.{weight,bias},
+   net.layers.i.{weight,bias}, net.out_layer.weight (shape check only), optional net.colvec [512]. */
+int fc_op_mlp_hidden_f32(const float* x0, int32_t k0, const float* x1, int32_t k1, const float* rowscal, const fc_tensor* tensors, int32_t n_tensors,
+                         float* out, int32_t rows, int32_t act, int32_t use_rows, void* stream) {
+    FC_API_BEGIN
+    using namespace fc;
+    if (!x0 || !out || rows < 1 || k0 < 1 || k1 < 0 || (k1 > 0 && !x1)) throw Error(FC_ERR_INVALID, "fc_op_mlp_hidden_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    WeightTable wt(tensors, n_tensors);
+    DeviceArena arena;
+    PackedMLP m;
+    pack_mlp_mid(arena, wt, "net", m);
+    const int H = m.sizes[0], p0 = round_up(k0, 32), p1 = k1 > 0 ? round_up(k1, 32) : 0;
+    for (int h : m.sizes) if (h != 512) throw Error(FC_ERR_UNSUPPORTED, "fc_op_mlp_hidden_f32: hidden width must be 512");
+    {
+        const HostTensor& w = wt.get("net.in_layer.weight", {H, k0 + k1});
+        std::vector<int> km = map_prefix(k0, p0);
+        for (int j = 0; j < p1; ++j) km.push_back(j < k1 ? k0 + j : -1);
+        VecD cv;
+        if (wt.has("net.colvec")) cv = vec_from(wt.get("net.colvec", {H}));
+        std::vector<int> segk = {p0};
+        if (p1) segk.push_back(p1);
+        m.in_layer = pack_linear(arena, mat_from(w), vec_from(wt.get("net.in_layer.bias", {H})), cv, map_prefix(H, H), km, segk);
+    }
+    attach_mlp_rows_images(arena, m);
+    const int rp = round_up(rows, ROW_PAD);
+    TmpBuf xa((size_t)rp * p0 * 4), xb((size_t)rp * std::max(p1, 32) * 4), h0((size_t)rp * 512 * 4), h1((size_t)rp * 512 * 4), h2((size_t)rp * 512 * 4),
+        h16((size_t)rp * 512 * 4), flag(sizeof(int)), rs((size_t)rp * 4);
+    launch_fill(xa.f(), 0.f, (size_t)rp * p0, s);
+    launch_fill(xb.f(), 0.f, (size_t)rp * std::max(p1, 32), s);
+    launch_fill(rs.f(), 0.f, (size_t)rp, s);
+    launch_pack_rows(x0, k0, k0, xa.f(), p0, 0, k0, rows, s);
+    if (k1 > 0) launch_pack_rows(x1, k1, k1, xb.f(), p1, 0, k1, rows, s);
+    if (rowscal) launch_pack_rows(rowscal, 1, 1, rs.f(), 1, 0, 1, rows, s);
+    float* const h[3] = {h0.f(), h1.f(), h2.f()};
+    ASeg segs[2] = {{xa.f(), p0}, {xb.f(), std::max(p1, 32)}};
+    const float* rsp = rowscal && m.in_layer.colvec ? rs.f() : nullptr;
+    FC_HIP(hipDeviceSynchronize());                       // (the images were built on the null stream)
+    run_fp16_guarded((int*)flag.p, s, [&] {
+        if (use_rows) launch_mlp_rows(m.in_layer, m.mid, segs, rsp, act, h, (unsigned short*)h16.p, rp, rows, s);
+        else if (run_mlp_hidden_generic(m, segs, rsp, act, h, 512, rp, s, rows, (unsigned short*)h16.p) != -1)
+            throw Error(FC_ERR_INVALID, "fc_op_mlp_hidden_f32: the limb chain is off");
+    });
+    launch_limb_decode((const unsigned short*)h16.p, out, 512, rows, 512, s);
     FC_HIP(hipStreamSynchronize(s));
     FC_API_END
 }

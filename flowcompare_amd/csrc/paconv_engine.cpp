@@ -298,9 +298,9 @@ int fc_paconv_embed_f32(fc_paconv* emb, const float* pts, float* out, int32_t B,
     FC_API_BEGIN
     if (!emb || !workspace) throw fc::Error(FC_ERR_INVALID, "fc_paconv_embed_f32: null handle / workspace");
     // fast split-fp16 GEMMs first; the whole pass is repeated with the bf16-limb GEMMs if an activation left fp16's range
-    fc::run_fp16_guarded(emb->fp16_flag, (hipStream_t)stream, [&] {
+    fc::run_fp16_guarded(emb->fp16_flag, (hipStream_t)stream, [=] {
         fc::paconv_forward(*emb, pts, out, B, M, workspace, workspace_bytes, (hipStream_t)stream);
-    });
+    }, true);
     FC_API_END
 }
 int fc_op_fps_f32(const float* xyz, int32_t* idx, int32_t B, int32_t n, int32_t m, void* stream) {

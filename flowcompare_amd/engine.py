@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FCFLOW_LIB", os.path.join(_HERE, "libfcflow.so"))   # FCFLOW_LIB: A/B another build in profiles/kernel_bench.py
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 FLOW_TYPES = {"AffineCoupling": 0, "RationalQuadraticSplineCoupling": 1, "ExponentialCoupling": 2}
 SCALE_FNS = {"exp": 0, "sigmoid": 1}
@@ -25,8 +25,9 @@ EXPORTS = [
     "fc_flow_logprob_f32", "fc_flow_inverse_f32",
     "fc_dgcnn_create", "fc_dgcnn_destroy", "fc_dgcnn_out_dim", "fc_dgcnn_workspace_bytes", "fc_dgcnn_embed_f32",
     "fc_paconv_create", "fc_paconv_destroy", "fc_paconv_out_dim", "fc_paconv_workspace_bytes", "fc_paconv_embed_f32", "fc_op_fps_f32",
+    "fc_range_check_defer", "fc_range_check_resolve", "fc_range_check_pending",
     "fc_profile_enable", "fc_profile_reset", "fc_profile_filter", "fc_profile_report",
-    "fc_op_linear_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
+    "fc_op_linear_f32", "fc_op_mlp_hidden_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
     "fc_stage_fps_f32", "fc_stage_co_unit_sphere_f32", "fc_clamp_infs_f32", "fc_change_map_f32",
     "fc_train_linear_pack_bytes", "fc_train_linear_pack_f32", "fc_train_linear_fwd_f32", "fc_train_linear_dgrad_f32",
     "fc_train_linear_wgrad_ws_bytes", "fc_train_linear_wgrad_f32", "fc_train_act_fwd_f32", "fc_train_act_bwd_f32",
@@ -152,6 +153,45 @@ def _tensor_table(state_dict):
     return arr, keep
 
 
+# ---------------------------------------------------------------- deferred range check (include/fcflow.h)
+_deferred_keep = []          # tensors handed to passes that are still pending (inputs, outputs, workspaces must outlive them)
+
+
+class deferred_range_check:
+    """Context manager: inside it the flow / embedder entry points only enqueue their split-fp16 pass -- no stream synchronisation per
+    call, forwards queue back to back -- and the range flags are read when the block is left (or at `resolve()`).  `repeated` holds the
+    number of passes that had to be repeated on the bf16-limb loops: when it is not 0, tensors derived from the passes' outputs inside
+    the block (losses, ...) are stale and must be recomputed from the outputs, which the repeats rewrote in place."""
+
+    def __init__(self):
+        self.repeated = 0
+
+    def __enter__(self):
+        _check(lib().fc_range_check_defer(1))
+        return self
+
+    def resolve(self):
+        n = ctypes.c_int32(0)
+        _check(lib().fc_range_check_resolve(ctypes.byref(n)))
+        del _deferred_keep[:]
+        self.repeated += n.value
+        return n.value
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                self.resolve()
+        finally:
+            lib().fc_range_check_defer(0)
+            del _deferred_keep[:]
+        return False
+
+
+def _keep_if_deferred(*tensors):
+    if lib().fc_range_check_pending() > 0:
+        _deferred_keep.extend(t for t in tensors if t is not None)
+
+
 class _Workspace:
     """Grow-only device scratch owned by a handle (the C ABI never allocates inside compute calls)."""
     def __init__(self):
@@ -237,6 +277,7 @@ class FlowHandle:
             eps_arr = (ctypes.c_void_p * max(1, len(eps)))(*[e.data_ptr() for e in eps])
             _check(L.fc_flow_logprob_f32(self._h, _ptr(x), _ptr(ctx), _ptr(extra), eps_arr, len(eps), _ptr(out), _ptr(z),
                                          B, N, M, _ptr(ws), ctypes.c_size_t(ws.numel()), _stream()))
+            _keep_if_deferred(x, ctx, extra, out, z, ws, *eps)
         return (out, z) if return_latent else out
 
     def inverse(self, z, context, extra_context, eps):
@@ -303,6 +344,7 @@ class DgcnnHandle:
             shape = (B, self.out_dim) if self.is_global else (B, M, self.out_dim)
             out = torch.empty(shape, dtype=torch.float32, device=self.device)
             _check(L.fc_dgcnn_embed_f32(self._h, _ptr(pts), _ptr(out), B, M, _ptr(ws), ctypes.c_size_t(ws.numel()), _stream()))
+            _keep_if_deferred(pts, out, ws)
         return out
 
 
@@ -337,6 +379,7 @@ class PaconvHandle:
             ws = self._ws.get(need.value, self.device)
             out = torch.empty(B, M, self.out_dim, dtype=torch.float32, device=self.device)
             _check(L.fc_paconv_embed_f32(self._h, _ptr(pts), _ptr(out), B, M, _ptr(ws), ctypes.c_size_t(ws.numel()), _stream()))
+            _keep_if_deferred(pts, out, ws)
         return out
 
 
@@ -410,6 +453,23 @@ def op_linear(x, W, bias=None, residual=None, act="none"):
     with torch.cuda.device(x.device):
         _check(lib().fc_op_linear_f32(_ptr(x), _ptr(W), _ptr(b), _ptr(r), _ptr(y), rows, N, K, code, _stream()))
     return y
+
+
+def op_mlp_hidden(x0, x1, state_dict, rowscal=None, act="gelu", use_rows=True):
+    """Last hidden activation [rows, 512] of a 512-wide reference MLP over cat(x0, x1) (fc_op_mlp_hidden_f32); `state_dict` holds
+    net.in_layer / net.layers.<i> / net.out_layer tensors (host or device; copied to the host), optionally net.colvec."""
+    code = {"none": 0, "gelu": 1, "relu": 2, "elu": 3, "lrelu": 4}[act]
+    x0 = _dev_f32(x0)
+    x1 = _dev_f32(x1) if x1 is not None else None
+    rs = _dev_f32(rowscal) if rowscal is not None else None
+    rows = x0.shape[0]
+    out = torch.empty(rows, 512, dtype=torch.float32, device=x0.device)
+    arr, keep = _tensor_table({k: v.detach().cpu() for k, v in state_dict.items()})
+    with torch.cuda.device(x0.device):
+        _check(lib().fc_op_mlp_hidden_f32(_ptr(x0), x0.shape[1], _ptr(x1), x1.shape[1] if x1 is not None else 0, _ptr(rs), arr, len(arr),
+                                          _ptr(out), rows, code, int(bool(use_rows)), _stream()))
+    del keep
+    return out
 
 
 def op_attention(q, k, v, scale):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 4
+#define FC_ABI_VERSION 5
 
 enum fc_status {
     FC_OK = 0,
@@ -169,6 +169,20 @@ int fc_clamp_infs_f32(float* t, int64_t n, void* stream);
 int fc_change_map_f32(float* lp10, int32_t N, float* lp00, int32_t N0, float* out, int32_t B, float multiple, float hard_cutoff,
                       int32_t use_cutoff, int32_t* invalid, void* stream);
 
+/* ---- deferred range check ------------------------------------------------------------------------
+ * The split-fp16 matrix loops cannot hold |activation| >= 65504: fc_flow_logprob_f32, fc_dgcnn_embed_f32 and
+ * fc_paconv_embed_f32 run their fast pass, read one device flag back and, if it is set, repeat the whole pass on the unbounded-range
+ * bf16-limb loops.  By default the read-back is a stream synchronisation inside the call.  With the calling thread's switch ON the call
+ * only ENQUEUES the fast pass, a 4-byte copy of the flag into pinned host memory and an event, and returns: any number of forwards can be
+ * queued back to back on one stream.  fc_range_check_resolve then visits the queued passes in order, waits for each pass's event and
+ * repeats it if its flag is set (a pass behind a repeated one is repeated too: it may have consumed the other's output); *n_repeated (may be
+ * NULL) receives the number of repeated passes.  Contract while passes are pending: their inputs, outputs and workspaces stay allocated
+ * and are not written by the caller, and anything computed from their outputs is provisional until resolve has returned 0 repeats.
+ * Switching the mode off resolves what is pending.  The state is per host thread. */
+int fc_range_check_defer(int32_t on);
+int fc_range_check_resolve(int32_t* n_repeated);
+int32_t fc_range_check_pending(void);
+
 /* ---- in-library kernel timing (used by bench.py for the roofline object) --------------------- */
 /* When enabled, every kernel launch of this library is bracketed by HIP events on its launch stream.
  * fc_profile_report writes a JSON array [{"kernel", "launches", "ms", "flops", "bytes"}, ...] (kernel names as
@@ -186,6 +200,15 @@ int fc_profile_report(char* buf, size_t cap);
  * (models/nets.py:19-30 building block).  bias / residual may be NULL.  All DEVICE pointers, dense row-major. */
 int fc_op_linear_f32(const float* x, const float* W, const float* bias, const float* residual, float* y,
                      int32_t rows, int32_t N, int32_t K, int32_t act, void* stream);
+
+/* The in_layer and hidden layers of one reference MLP (models/nets.py:19-30: act(in_layer(x)); even hidden layer i: keep = x, x = act(W x + b);
+ * odd: x = act(keep + W x + b)) at hidden width 512 -- the coupling nets of models/affine_coupling.py:30-46 / models/spline_coupling.py:187-210
+ * -- over cat(x0 [rows,k0], x1 [rows,k1]) (+ rowscal[row] * net.colvec, the rank-1 form of an extra-context column).  out [rows,512] = the last
+ * hidden activation (what out_layer consumes).  use_rows != 0: the row-resident chain kernel (one launch, csrc/mlprows.hip), 0: one GEMM
+ * launch per layer.  tensors are HOST fp32: net.in_layer.{weight,bias}, net.layers.<i>.{weight,bias}, net.out_layer.weight (shape check
+ * only), optional net.colvec [512]; x0 / x1 / rowscal / out are DEVICE pointers (x1, rowscal may be NULL). */
+int fc_op_mlp_hidden_f32(const float* x0, int32_t k0, const float* x1, int32_t k1, const float* rowscal, const fc_tensor* tensors,
+                         int32_t n_tensors, float* out, int32_t rows, int32_t act, int32_t use_rows, void* stream);
 
 /* out[B,N,D] = softmax(q k^T * scale) v  with q [B,N,D], k,v [B,M,D]  (models/perceiver.py:106-113). */
 int fc_op_attention_f32(const float* q, const float* k, const float* v, float* out,

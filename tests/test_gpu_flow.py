@@ -194,6 +194,56 @@ def test_out_of_fp16_range_activations_repeat_on_the_bf16_limb_path():
         assert torch.isfinite(lp).all() and err < PER_POINT_TOL and abs(float(bpd) - float(fx.a["bpd_f64"])) < BPD_TOL
 
 
+def test_deferred_range_check_queues_forwards_back_to_back_and_still_repeats_out_of_range_passes():
+    """fc_range_check_defer (include/fcflow.h): inside `engine.deferred_range_check()` the embedder and flow entry points only enqueue their
+    fast pass (no stream synchronisation per call); the flags are read at resolve.  (i) Two forwards queued back to back equal the
+    synchronously checked ones bit for bit and nothing is repeated; (ii) a pass that leaves fp16's range (the alpha = 1e6 ReLU net of the
+    test above) is repeated at resolve on the bf16-limb loops, its output is rewritten in place and matches the golden."""
+    import ctypes
+    from flowcompare_amd import engine
+    lib = engine.lib()
+    lib.fc_debug_fp16_fallbacks.restype = ctypes.c_int64
+    fx = Fixture("e2e_tiny_spline_relu")
+    cfg = dict(fx.cfg)
+    sd_flow, sd_emb = fx.state_dicts()
+    batch = tuple(t.to(DEV) for t in (fx.t("extract_0"), fx.t("extract_1"), fx.t("extra")))
+    batch2 = (batch[0].flip(0).contiguous(), batch[1].flip(0).contiguous(), None if batch[2] is None else batch[2].flip(0).contiguous())
+    eps = [e.to(DEV) for e in fx.eps()]
+    eps2 = [e.flip(0).contiguous() for e in eps]
+    ref = torch.from_numpy(fx.a["log_prob_f64"])
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    fa.load_flow({"flow": sd_flow, "input_embedder": sd_emb}, md)
+    _, lp_a, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+    _, lp_b, _ = fa.inner_loop(batch2, md, cfg, eps=eps2)
+    with engine.deferred_range_check() as drc:
+        _, q_a, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+        assert lib.fc_range_check_pending() == 2                  # embedder pass + flow pass, neither waited for
+        _, q_b, _ = fa.inner_loop(batch2, md, cfg, eps=eps2)
+        assert lib.fc_range_check_pending() == 4
+    assert drc.repeated == 0 and lib.fc_range_check_pending() == 0
+    assert torch.equal(q_a, lp_a) and torch.equal(q_b, lp_b)
+    # (ii) out-of-range hidden activations
+    sd = {k: v.clone() for k, v in sd_flow.items()}
+    pre = "transforms.4.transform.nn."
+    for k in sd:
+        if k.startswith(pre + "in_layer.") or (k.startswith(pre + "layers.") and k.endswith(".bias")):
+            sd[k] = sd[k] * 1.0e6
+        elif k == pre + "out_layer.weight":
+            sd[k] = sd[k] / 1.0e6
+    md = fa.initialize_flow(cfg, device=DEV, mode="test")
+    fa.load_flow({"flow": sd, "input_embedder": sd_emb}, md)
+    before = lib.fc_debug_fp16_fallbacks()
+    with engine.deferred_range_check() as drc:
+        _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+        _, lp2, _ = fa.inner_loop(batch2, md, cfg, eps=eps2)
+    torch.cuda.synchronize()
+    assert drc.repeated >= 2 and lib.fc_debug_fp16_fallbacks() >= before + 2
+    err = (lp.cpu().double() - ref).abs().max().item()
+    err2 = (lp2.flip(0).cpu().double() - ref).abs().max().item()
+    print(f"deferred check: {drc.repeated} passes repeated at resolve, max |log-prob - fp64 golden| {err:.2e} / {err2:.2e}")
+    assert torch.isfinite(lp).all() and err < PER_POINT_TOL and err2 < PER_POINT_TOL
+
+
 def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     """The shipped fast paths (split-fp16 GEMM on eight-wave tiles, fused spline epilogue, split-fp16 attention) against the
     variants they replaced or that lost an A/B (fused pre-attention chain kernel), which stay in the library: same log-probs within the
@@ -208,10 +258,10 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
     eps = [torch.randn(B, N, 294, generator=g).to(DEV)]
     batch = (e0.to(DEV), e1.to(DEV), None)
-    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 2, 9: 1, 10: 1, 13: 4, 15: 2, 16: 1, 17: 0, 19: 0, 21: 0, 22: 1}
+    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 2, 9: 1, 10: 1, 13: 4, 15: 2, 16: 1, 17: 0, 19: 0, 21: 0, 22: 1, 23: 1}
     try:
         _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
-        for name, knobs in (("unfused spline", {7: 0}), ("LDS-tile pre-attention chain kernel", {8: 1}), ("separate pre-attention GEMM launches + LayerNorm -> q fold", {8: 0}), ("separate LayerNorm + q projection", {8: 0, 10: 0}), ("no limb chain", {9: 0}), ("limb chain into the spline GEMM only", {16: 0}), ("limb-chained pre-attention MLP", {8: 0, 19: 1}), ("limb-chained hidden layers on the register-staged tile", {15: 0}), ("limb-chained hidden layers on the 256x128 DMA tile", {15: 1}), ("fp32-input attention", {5: 0}),
+        for name, knobs in (("one GEMM launch per coupling-MLP layer instead of the row-resident chain", {23: 0}), ("unfused spline", {7: 0}), ("LDS-tile pre-attention chain kernel", {8: 1}), ("separate pre-attention GEMM launches + LayerNorm -> q fold", {8: 0}), ("separate LayerNorm + q projection", {8: 0, 10: 0}), ("no limb chain", {9: 0}), ("limb chain into the spline GEMM only", {16: 0}), ("limb chain into the spline GEMM only, per-layer launches", {23: 0, 16: 0}), ("limb-chained pre-attention MLP", {8: 0, 19: 1}), ("limb-chained hidden layers on the register-staged tile", {23: 0, 15: 0}), ("limb-chained hidden layers on the 256x128 DMA tile", {23: 0, 15: 1}), ("fp32-input attention", {5: 0}),
                             ("four-wave tile", {3: 0}), ("256x128 tile", {3: 2}), ("bf16-limb GEMM", {0: 3}), ("fp32-input MFMA GEMM", {0: 2})):
             for k, v in knobs.items():
                 lib.fc_debug_set(k, v)

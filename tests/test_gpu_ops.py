@@ -38,6 +38,71 @@ def test_linear_matches_fp64(rows, N, K, act, res):
     assert (y - ref).abs().max().item() < 2e-6 * max(1.0, K ** 0.5)
 
 
+def _mlp_state(k_in, n_mid, seed, colvec=False):
+    g = torch.Generator().manual_seed(seed)
+    u = lambda *sh, sc=1.0: (torch.rand(*sh, generator=g) * 2 - 1) * sc
+    sd = {"net.in_layer.weight": u(512, k_in, sc=(3.0 / k_in) ** 0.5), "net.in_layer.bias": u(512, sc=0.2),
+          "net.out_layer.weight": torch.zeros(1, 512)}
+    for i in range(n_mid):
+        sd[f"net.layers.{i}.weight"] = u(512, 512, sc=(3.0 / 512) ** 0.5 * 1.5)
+        sd[f"net.layers.{i}.bias"] = u(512, sc=0.2)
+    if colvec:
+        sd["net.colvec"] = u(512, sc=0.1)
+    return sd
+
+
+def _mlp_ref(x, sd, n_mid, rowscal=None):
+    """models/nets.py:19-30 in fp64: act(in_layer); even hidden layer keeps its input, odd adds it back before the activation."""
+    F = torch.nn.functional
+    h = F.linear(x.double(), sd["net.in_layer.weight"].double(), sd["net.in_layer.bias"].double())
+    if rowscal is not None:
+        h = h + rowscal.double()[:, None] * sd["net.colvec"].double()[None]
+    h = F.gelu(h)
+    keep = None
+    for i in range(n_mid):
+        z = F.linear(h, sd[f"net.layers.{i}.weight"].double(), sd[f"net.layers.{i}.bias"].double())
+        if i % 2 == 0:
+            keep = h
+            h = F.gelu(z)
+        else:
+            h = F.gelu(keep + z)
+    return h
+
+
+@pytest.mark.parametrize("rows,k0,k1,n_mid,extra", [(1000, 150, 64, 2, False), (515, 150, 124, 5, False), (300, 150, 64, 2, True),
+                                                     (4096, 150, 64, 2, False), (129, 150, 124, 4, False), (64, 256, 200, 3, False)])
+def test_row_resident_mlp_chain_matches_fp64_and_the_per_layer_launches(rows, k0, k1, n_mid, extra):
+    """csrc/mlprows.hip (in_layer + hidden layers of a 512-wide coupling net in one launch, activations resident in registers) against
+    fp64 and against the limb-chained per-layer GEMM launches it replaces: same limb products in the same k order, so the two HIP paths
+    differ only by where the residual is added (fp32 rounding), and both sit at the split-fp16 GEMM's distance from fp64."""
+    sd = _mlp_state(k0 + k1, n_mid, seed=rows + n_mid, colvec=extra)
+    x0, x1 = _rand(rows, k0, seed=11, scale=2.0), _rand(rows, k1, seed=12, scale=1.5)
+    rs = (_rand(rows, seed=13) * 7 + 7.5) if extra else None
+    ref = _mlp_ref(torch.cat((x0, x1), 1), sd, n_mid, rs)
+    args = (x0.to(DEV), x1.to(DEV), sd, None if rs is None else rs.to(DEV))
+    y_rows = engine.op_mlp_hidden(*args, use_rows=True).cpu().double()
+    y_gemm = engine.op_mlp_hidden(*args, use_rows=False).cpu().double()
+    scale = ref.abs().max().item()
+    e_rows, e_gemm, e_ab = (y_rows - ref).abs().max().item(), (y_gemm - ref).abs().max().item(), (y_rows - y_gemm).abs().max().item()
+    print(f"rows {rows} K {k0}+{k1} hidden layers {n_mid}: |chain - fp64| {e_rows:.2e}  |per-layer - fp64| {e_gemm:.2e}  |chain - per-layer| {e_ab:.2e}  (max |h| {scale:.2f})")
+    assert e_gemm < 2e-5 * max(1.0, scale) and e_rows < 2e-5 * max(1.0, scale)
+    assert e_ab < 4e-6 * max(1.0, scale)
+    y2 = engine.op_mlp_hidden(*args, use_rows=True).cpu().double()
+    assert torch.equal(y2, y_rows), "the row-resident chain is not deterministic"
+
+
+def test_row_resident_mlp_chain_rows_are_independent():
+    """Each wave of the chain kernel owns 32 rows for the whole chain: a row's result must not depend on which band / workgroup it sits in."""
+    sd = _mlp_state(214, 2, seed=5)
+    x0, x1 = _rand(700, 150, seed=21, scale=2.0), _rand(700, 64, seed=22)
+    full = engine.op_mlp_hidden(x0.to(DEV), x1.to(DEV), sd).cpu()
+    perm = torch.randperm(700, generator=torch.Generator().manual_seed(3))
+    shuf = engine.op_mlp_hidden(x0[perm].to(DEV), x1[perm].to(DEV), sd).cpu()
+    assert torch.equal(shuf, full[perm])
+    part = engine.op_mlp_hidden(x0[37:300].to(DEV), x1[37:300].to(DEV), sd).cpu()
+    assert torch.equal(part, full[37:300])
+
+
 def test_linear_is_linear_and_exact_on_integers():
     """Integer-valued operands make every partial sum exact in fp32: the MFMA path must be bit-exact, which
     catches any fragment-layout / k-mapping mistake (asymmetric W so a transposed store cannot pass)."""
