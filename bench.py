@@ -65,11 +65,33 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """File-descriptor level: RCCL prints its version banner to stdout when a communicator is created; stdout carries only the JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def init_rccl(dist, dev, **kw):
+    with stdout_to_stderr():
+        dist.init_process_group("nccl", device_id=dev, **kw)
+        t = torch.zeros(1, device=dev)
+        dist.all_reduce(t)                                # the communicator (and its banner) come with the first collective
+        torch.cuda.synchronize()
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(cfg, md, points, seed):
+def cpu_baseline(cfg, md, points, seed, sd=None):
     """The pinned CPU oracle (oracle/flow_oracle.py, fp32, eager PyTorch on the host cores) on ONE scene of the workload."""
     from oracle import flow_oracle as O
     cores = host_cores()
@@ -77,8 +99,8 @@ def cpu_baseline(cfg, md, points, seed):
     log(f"cpu_baseline: oracle on {cores} host threads, 1 scene x {points} points ...")
     c = dict(cfg)
     c["sample_size"] = points
-    sd_f = {k: v.detach().cpu() for k, v in md["flow"].state_dict().items()}
-    sd_e = {k: v.detach().cpu() for k, v in md["input_embedder"].state_dict().items()}
+    sd_f, sd_e = sd if sd is not None else ({k: v.detach().cpu() for k, v in md["flow"].state_dict().items()},
+                                            {k: v.detach().cpu() for k, v in md["input_embedder"].state_dict().items()})
     e0, e1, ex, g = synth_pairs(1, points, points, seed, "cpu")
     eps = [torch.randn(1, points, c["latent_dim"] - c["input_dim"], generator=g)] if c["latent_dim"] > c["input_dim"] else []
     batch = (e0, e1, ex if c["extra_z_value_context"] else None)
@@ -91,9 +113,16 @@ def cpu_baseline(cfg, md, points, seed):
                       f"{dt:.1f} s of host time"}, lp
 
 
-def train_main(args, cfg, md, batch, eps, dist, world, rank, dev):
-    """bench.py --train: W warm-up + K timed training steps per rank on its own scenes (weak scaling), barrier + synchronize on both sides,
-    MAX over ranks; the one exchange step is the bucketed RCCL SUM all-reduce of the gradients (flowcompare_amd/shard.py)."""
+def fp16_fallbacks():
+    import ctypes
+    L = engine.lib()
+    L.fc_debug_fp16_fallbacks.restype = ctypes.c_int64
+    return int(L.fc_debug_fp16_fallbacks())
+
+
+def train_steps(args, cfg, md, batch, eps, dist, world, rank, dev, steps, warmup):
+    """W warm-up + K timed training steps per rank on its own scenes (weak scaling), barrier + synchronize on both sides, MAX over ranks;
+    the one exchange step is the bucketed RCCL SUM all-reduce of the gradients (flowcompare_amd/shard.py).  Returns the result dict."""
     md["flow"].train()
     md["input_embedder"].train()
     params = [p for p in md["parameters"] if p.requires_grad]
@@ -101,33 +130,51 @@ def train_main(args, cfg, md, batch, eps, dist, world, rank, dev):
     opt = shard.FlatAdam(reducer, lr=1e-5)                # clip_grad_norm_ + Adam as HIP kernels on the reducer's flat buffers
     B, N = batch[1].shape[0], batch[1].shape[1]
     n_global = world * B * N
-    loss = None
-    for i in range(args.warmup):
-        loss, lp, bpd, norm = shard.local_training_step(batch, n_global, md, cfg, reducer, optimizer=opt, eps=eps)
+    loss = norm = None
+    fb0 = fp16_fallbacks()
+    try:
+        for i in range(warmup):
+            loss, lp, bpd, norm = shard.local_training_step(batch, n_global, md, cfg, reducer, optimizer=opt, eps=eps)
+            torch.cuda.synchronize()
+            log(f"rank {rank}: training warmup step {i}: loss {float(loss):.4f} |grad| {float(norm):.3e} peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+        dist.barrier()
         torch.cuda.synchronize()
-        log(f"rank {rank}: training warmup step {i}: loss {float(loss):.4f} |grad| {float(norm):.3e} peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, lp, bpd, norm = shard.local_training_step(batch, n_global, md, cfg, reducer, optimizer=opt, eps=eps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor(dt, device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, lp, bpd, norm = shard.local_training_step(batch, n_global, md, cfg, reducer, optimizer=opt, eps=eps)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor(dt, device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    finally:
+        reducer.remove()
+        md["flow"].eval()
+        md["input_embedder"].eval()
+    n_par = sum(p.numel() for p in reducer.params)
+    return {"ms_per_step": dt / steps * 1e3, "points_per_sec": n_global * steps / dt, "steps": steps, "warmup": warmup,
+            "loss": float(loss), "grad_norm": float(norm), "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30,
+            "fp16_fallbacks": fp16_fallbacks() - fb0,
+            "what": "forward + backward (HIP training kernels) + bucketed RCCL gradient all-reduce + clip_grad_norm_ + Adam, embedder in train() mode "
+                    "(train.py:108-120)",
+            "gradient_all_reduce": f"{len(reducer.buckets)} buckets over {n_par * 4 / 2**20:.0f} MiB (RCCL), world {world}"}
+
+
+def train_main(args, cfg, md, batch, eps, dist, world, rank, dev):
+    """bench.py --train: the training step as its own JSON line."""
+    r = train_steps(args, cfg, md, batch, eps, dist, world, rank, dev, args.steps, args.warmup)
+    B, N = batch[1].shape[0], batch[1].shape[1]
     if rank == 0:
-        n_par = sum(p.numel() for p in reducer.params)
         print(json.dumps({
-            "metric": "points/sec (training step: forward + backward + RCCL gradient all-reduce + clip + Adam, all HIP kernels)", "value": n_global * args.steps / dt,
-            "unit": "points/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "points/sec (training step: forward + backward + RCCL gradient all-reduce + clip + Adam, all HIP kernels)", "value": r["points_per_sec"],
+            "unit": "points/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16x2 split (fp32-equivalent operands, f32 accumulate) / f32",
-            "data": "synthetic (conditioned random-init weights)",
+            "data": "synthetic (conditioned random-init weights)", "weights": args.weights, "fp16_fallbacks": r["fp16_fallbacks"],
             "config": {"workload": f"{args.config}: batch {B} scenes/GPU x {N} target + {N} context points, {cfg['n_flow_layers']} flow layers, embedder trained",
                        "global_batch": world * B, "points_per_scene": N,
-                       "parallelism": f"scene-sharded x{world}; gradient all-reduce: {len(reducer.buckets)} buckets over {n_par * 4 / 2**20:.0f} MiB (RCCL)"},
-            "loss": float(loss), "grad_norm": float(norm), "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30}), flush=True)
+                       "parallelism": f"scene-sharded x{world}; gradient all-reduce: {r['gradient_all_reduce']}"},
+            "loss": r["loss"], "grad_norm": r["grad_norm"], "peak_mem_GiB": r["peak_mem_GiB"]}), flush=True)
     dist.destroy_process_group()
 
 
@@ -149,6 +196,12 @@ def main():
                          "gradient all-reduce overlapped with backward, clip_grad_norm_, Adam; embedder in train() mode.  Prints its own JSON line "
                          "(metric 'points/sec (training step ...)'); the default forward metric is BASELINE.json's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=2,
+                    help="timed training steps of the `train` object that the default (forward) line carries: after the forward region, one warm-up + "
+                         "this many timed training steps of the same workload (0 = leave the object out)")
+    ap.add_argument("--sync-range-check", action="store_true",
+                    help="diagnostic: the round-2 behaviour -- every forward call reads its fp16 range flag back (one stream synchronisation per call) "
+                         "instead of the deferred check (fc_range_check_defer: K forwards queued back to back, flags read once at the end of the timed region)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: leave the in-library HIP-event profiler off in the timed region")
     ap.add_argument("--knob", action="append", default=[], help="K=V tuning knob for same-box A/B runs (fc_debug_set); not for headline numbers")
     ap.add_argument("--cpu-points", type=int, default=None, help="points per scene of the CPU sample (default: same as --points)")
@@ -171,12 +224,12 @@ def main():
     dist = None
     if world > 1 or "RANK" in os.environ:             # under torch.distributed.run (also with one rank: exercises the RCCL path)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-    elif args.train:                                  # the training step's exchange is RCCL's also on one GPU (a one-rank group)
+        init_rccl(dist, dev)
+    elif args.train or args.train_steps > 0:          # the training step's exchange is RCCL's also on one GPU (a one-rank group)
         import socket
         import torch.distributed as dist
         sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        init_rccl(dist, dev, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
 
     over = {"sample_size": args.points}
     if args.layers:
@@ -233,25 +286,41 @@ def main():
     engine.profile_reset()
     engine.profile_filter(dominant)
     engine.profile_enable(not args.no_profile)
+    fb0 = fp16_fallbacks()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, lp, bpd = step()
+    # Deferred range check (include/fcflow.h fc_range_check_defer): the K forwards are queued back to back on the stream, each followed by a
+    # 4-byte copy of its split-fp16 range flag into pinned host memory; leaving the block reads the flags in order (and would repeat an
+    # out-of-range pass on the bf16-limb loops) -- INSIDE the timed region, so the K steps are complete and checked when the clock stops.
+    with (contextlib.nullcontext() if args.sync_range_check else engine.deferred_range_check()) as drc:
+        for _ in range(args.steps):
+            loss, lp, bpd = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    repeated = drc.repeated if drc is not None else 0
+    if repeated:                                          # outputs were rewritten in place by the repeats: recompute the scalars from them
+        loss = -lp.mean()
+        bpd = loss * math.log2(math.e) / cfg["input_dim"]
+    fallbacks = fp16_fallbacks() - fb0
     engine.profile_enable(False)
     engine.profile_filter(None)
     prof = engine.profile_report()
-    log(f"rank {rank}: {args.steps} timed steps in {dt:.3f} s")
+    log(f"rank {rank}: {args.steps} timed steps in {dt:.3f} s ({fallbacks} passes repeated on the bf16-limb loops)")
     if dist is not None:
         t = torch.tensor(dt, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+    mean_nats, bpd_f = float(-loss), float(bpd)
+    sd = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the weights the forward ran on (the training leg below updates them)
+        sd = ({k: v.detach().cpu().clone() for k, v in md["flow"].state_dict().items()},
+              {k: v.detach().cpu().clone() for k, v in md["input_embedder"].state_dict().items()})
 
+    out = None
     if rank == 0 and args.no_profile:
         print(json.dumps({"diagnostic": "profiler off", "value": world * B * N * args.steps / dt, "ms_per_step": dt / args.steps * 1e3}), flush=True)
     elif rank == 0:
@@ -268,19 +337,22 @@ def main():
             var = next((v for v in SPLIT_MFMA_PER_PRODUCT if dom["kernel"].endswith(f", {v}>(fc::GemmParams)")), None)   # ..., VAR>
             if var is None and "attn16_kernel" in dom["kernel"]:
                 var = 5                                     # split-fp16 attention: 3 limb products per fp32-equivalent product in QK^T and in PV
+            # achieved = ALGORITHMIC fp32-equivalent FLOPs of the launches / their time, against the dense 16-bit MFMA peak the
+            # loop runs on.  The split loops issue n limb products per fp32-equivalent product: that issue rate is reported beside it as
+            # frac_issued (what the matrix pipes are asked to do), never as frac.
             if var is not None:
                 n = SPLIT_MFMA_PER_PRODUCT[var]
-                achieved, peak = useful * n, PEAK_BF16_MATRIX_TFLOPS
-                note = (f"split-{'fp16' if var != 3 else 'bf16'} loop: achieved = 16-bit MFMA FLOPs actually issued ({n} limb products per "
-                        "fp32-equivalent product, padding excluded) against the dense fp16/bf16 MFMA peak 2500 TFLOP/s; "
-                        "useful_fp32_equivalent_tflops is the same launch time priced in fp32-equivalent FLOPs (the fp32-input MFMA "
-                        "peak is 157.3 TFLOP/s)")
+                peak = PEAK_BF16_MATRIX_TFLOPS
+                note = (f"split-{'fp16' if var != 3 else 'bf16'} loop on the dense fp16/bf16 MFMA peak 2500 TFLOP/s: achieved = algorithmic fp32-equivalent "
+                        f"multiply-add FLOPs (padding excluded); the loop issues {n} limb products per fp32-equivalent product, so the 16-bit MFMA FLOPs "
+                        "actually issued are issued_tflops (frac_issued of the same peak); the fp32-input MFMA peak would be 157.3 TFLOP/s")
             else:
-                achieved, peak = useful, PEAK_F32_MATRIX_TFLOPS
+                n = 1
+                peak = PEAK_F32_MATRIX_TFLOPS
                 note = "fp32-input MFMA (v_mfma_f32_32x32x2_f32) against its dense peak 157.3 TFLOP/s"
-            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                    "frac": achieved / peak, "frac_algorithmic": useful / peak, "traffic": None, "useful_fp32_equivalent_tflops": useful,
-                    "frac_note": "frac = MFMA FLOPs issued / peak (issue rate); frac_algorithmic = algorithmic fp32-equivalent FLOPs (SURVEY.md 8d) / the same peak",
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": useful, "peak": peak, "unit": "TFLOP/s",
+                    "frac": useful / peak, "frac_issued": useful * n / peak, "issued_tflops": useful * n, "traffic": None,
+                    "frac_note": "frac = algorithmic fp32-equivalent FLOPs (SURVEY.md 8d) / peak; frac_issued = MFMA FLOPs issued / the same peak (issue rate)",
                     "peak_source": "MI355X_MICROARCH.md; " + note}
         else:
             achieved = dom["bytes"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e9
@@ -309,7 +381,8 @@ def main():
             "config": {"workload": f"{args.config}: batch {B} scenes/GPU x {N} target + {N} context points, "
                                    f"{cfg['n_flow_layers']} flow layers ({cfg['flow_type']}), embedder {cfg['input_embedder']}",
                        "global_batch": world * B, "points_per_scene": N, "parallelism": f"scene-sharded x{world}, no data-path collective"},
-            "mean_nats": float(-loss), "bpd": float(bpd),
+            "mean_nats": mean_nats, "bpd": bpd_f, "weights": args.weights, "fp16_fallbacks": fallbacks,
+            "range_check": "per call (stream synchronisation)" if args.sync_range_check else "deferred: flags of the K queued forwards read at the end of the timed region (fc_range_check_defer)",
             "job_algorithmic_tflops": None if alg is None or args.layers else alg * 1e6 * value / 1e12,
             "roofline": roof,
             "kernels_source": "HIP events around every launch of the last warmup step" if warm_prof else "timed region",
@@ -317,10 +390,35 @@ def main():
                          "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] else None,
                          "gbs": (p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["bytes"] else None} for p in breakdown[:8]],
         }
+
+    # `train` object: the training step of the same workload on the same clock (`bench.py --train` prints it as its own
+    # line).  Every rank takes part; the forward line is complete before it starts and is printed even if the leg fails or hangs.
+    if args.train_steps > 0 and not args.no_profile:
+        import threading
+        done = threading.Event()
+
+        def watchdog():                                   # a leg that hangs (a collective that never completes) must not take the forward line with it
+            if not done.wait(600.0):
+                log(f"rank {rank}: training leg exceeded 600 s -- abandoned")
+                if out is not None:
+                    out["train"] = {"error": "training leg abandoned after 600 s"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0 if out is not None else 3)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            torch.cuda.reset_peak_memory_stats()
+            train_obj = train_steps(args, cfg, md, batch, eps, dist, world, rank, dev, args.train_steps, 1)
+        except Exception as e:                            # noqa: BLE001 -- reported in the line, the forward numbers stand
+            train_obj = {"error": f"{type(e).__name__}: {e}"[:300]}
+            log(f"rank {rank}: training leg failed: {e}")
+        done.set()
+        if out is not None:
+            out["train"] = train_obj
+    if out is not None:
         if world == 1 and not args.no_cpu_baseline:
-            cb, _ = cpu_baseline(cfg, md, args.cpu_points or N, 1000)
+            cb, _ = cpu_baseline(cfg, md, args.cpu_points or N, 1000, sd)
             out["cpu_baseline"] = cb
-            out["gpu_over_cpu"] = value / cb["value"]
+            out["gpu_over_cpu"] = out["value"] / cb["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

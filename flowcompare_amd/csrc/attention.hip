@@ -449,12 +449,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 template <int DH>
 static void launch_attn16_dh(const Attn16Params& p, int B, hipStream_t s) {
     constexpr size_t lds = 2 * 64 * (size_t)(8 * DH + 80);
-    static bool attr_done = false;
+    static PerDeviceOnce attr_once;
     auto kern = attn16_kernel<DH>;
-    if (!attr_done) {
-        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); return 0; });
     char name[64];
     snprintf(name, sizeof name, "void fc::attn16_kernel<%d>(fc::Attn16Params)", DH);
     ProfScope ps(name, 4.0 * B * (double)p.N * (double)p.M * DH, 0.0, s);
@@ -465,12 +462,9 @@ static void launch_attn16_dh(const Attn16Params& p, int B, hipStream_t s) {
 template <int DH>
 static void launch_attn_dh(const AttnParams& p, int B, hipStream_t s) {
     constexpr size_t lds = 2 * 2 * 64 * (size_t)(DH + 4) * sizeof(float);
-    static bool attr_done = false;
+    static PerDeviceOnce attr_once;
     auto kern = attn_kernel<DH>;
-    if (!attr_done) {
-        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); return 0; });
     char name[64];
     snprintf(name, sizeof name, "void fc::attn_kernel<%d>(fc::AttnParams)", DH);
     ProfScope ps(name, 4.0 * B * (double)p.N * (double)p.M * DH, 0.0, s);

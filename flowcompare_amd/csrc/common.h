@@ -168,6 +168,24 @@ struct GemmEpi {
 // the calling thread: the scope hands the kernels a device flag they raise on such a value, and the entry point that opened the
 // scope repeats its whole computation with the bf16-limb loop (unbounded range) when the flag came back set.  Outside a scope
 // launch_gemm always takes the bf16-limb loop.
+// One-time setup per (call site, device) -- hipFuncSetAttribute for > 64 KB of dynamic LDS, the CU count behind a persistent grid: a process
+// may drive several devices and pack from a pool of host threads, so a process-wide `static bool done` is not enough.
+struct PerDeviceOnce {
+    std::mutex mu;
+    bool done[64] = {};
+    int value[64] = {};
+    // runs f(dev) the first time the calling thread's current device is seen here; returns what that call returned
+    template <class F>
+    int run(F&& f) {
+        int dev = 0;
+        FC_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 0 || dev >= 64) return f(dev);
+        if (!done[dev]) { value[dev] = f(dev); done[dev] = true; }
+        return value[dev];
+    }
+};
+
 struct Fp16Guard {
     Fp16Guard(int* dev_flag, hipStream_t s);
     ~Fp16Guard();

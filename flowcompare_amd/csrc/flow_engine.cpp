@@ -724,6 +724,13 @@ static Prep prepare(fc_flow& f, const float* ctx, const float* extra, int B, int
     return p;
 }
 
+// Diagnostic (fc_debug_flow_trace, ops_api.cpp; tests/fullsize_util.py): when the calling thread has set a buffer, flow_forward copies the
+// x2 half of the latent AS THE COUPLING OF LAYER l WILL READ IT into trace[l][row][d2] -- the fp32 values the spline's inside / outside
+// decision |x2| <= 3 is taken on (models/spline_coupling.py:35-48), so a test can hand the fp64 oracle the HIP run's own decisions.
+thread_local float* t_flow_trace = nullptr;
+thread_local size_t t_flow_trace_floats = 0;
+void flow_set_trace(float* buf, size_t floats) { t_flow_trace = buf; t_flow_trace_floats = floats; }
+
 static int expected_noise(const fc_flow& f) { return (f.has_augment ? 1 : 0) + (f.d.nz > 0 ? f.cfg.n_flow_layers : 0); }
 
 static void flow_forward(fc_flow& f, const float* x, const float* ctx, const float* extra, const float* const* eps, int n_eps,
@@ -773,6 +780,11 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
             GemmEpi es{};                                   // Slice: ldj += log N(actnorm(z2); mu(zx), sigma(zx))
             es.val = w.cbuf; es.ldval = d.nz_pad; es.val_shift = b.cif.z2_shift; es.val_scale = b.cif.z2_scale; es.logprob = logprob;
             run_cif_dist(f, b.cif, w, xc, es, EPI_SLICE, s);
+        }
+        if (t_flow_trace) {
+            if ((size_t)(l + 1) * w.P * d.d2 > t_flow_trace_floats) throw Error(FC_ERR_INVALID, "fc_debug_flow_trace: buffer too small for n_flow_layers x rows x d2");
+            FC_HIP(hipMemcpy2DAsync(t_flow_trace + (size_t)l * w.P * d.d2, (size_t)d.d2 * 4, xc + d.d1_pad, (size_t)d.ldx * 4, (size_t)d.d2 * 4, (size_t)w.P,
+                                    hipMemcpyDeviceToDevice, s));
         }
         run_coupling(f, b, w, xc, pr.rowscal, logprob, false, B, N, M, s);
         if (b.has_lin) {

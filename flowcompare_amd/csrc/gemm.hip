@@ -1275,14 +1275,11 @@ int guard_resolve() {
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
     constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : VAR == 11 ? 2 * (size_t)(BM + BN) * 128 + 1024 : (VAR == 9 || VAR == 10) ? 2 * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 6 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
-    static bool attr_done = false;
+    static PerDeviceOnce attr_once;
     constexpr size_t lds_epi = EPI == EPI_SPLINE && VAR != 10 && VAR != 11 ? ((size_t)BM * (BN + 1) + (size_t)BM * 9) * sizeof(float) : 0;   // tile + <= 9 dims of log-dets
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     auto kern = gemm_f32_kernel<BM, BN, WM, WN, EPI, VAR>;
-    if (!attr_done) {
-        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); return 0; });
     GemmParams q = p;
     q.nbn = (p.N_pad + BN - 1) / BN;
     q.col_group = 0;
@@ -1306,14 +1303,13 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
     ProfScope ps(name, p.e.flops_hint, 0.0, s);
     int grid = q.nbm * q.nbn;
     if constexpr (VAR == 11) {                                          // persistent: two workgroups per CU, a multiple of 8 (XCD order)
-        static int slots = 0;
-        if (!slots) {
-            int dev = 0, cus = 0;
-            FC_HIP(hipGetDevice(&dev));
+        static PerDeviceOnce slots_once;
+        const int slots = slots_once.run([](int dev) {
+            int cus = 0;
             FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            slots = (2 * cus) & ~7;
-            if (slots < 8) slots = 8;
-        }
+            const int n = (2 * cus) & ~7;
+            return n < 8 ? 8 : n;
+        });
         if (grid > slots) grid = slots;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, q);

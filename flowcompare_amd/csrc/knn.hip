@@ -162,11 +162,8 @@ void launch_knn(const float* f, int ldf, int C, int32_t* idx, int B, int M, int 
     if (ldf < Cp || ldf % 4 != 0 || ((uintptr_t)f & 15)) throw Error(FC_ERR_INVALID, "knn: feature pitch must cover round_up(C,4) and be 16-byte aligned");
     const size_t lds = ((size_t)(64 + 16) * (Cp + 4) + 16 + 16 * KNN_CAP) * sizeof(float) + 16 * KNN_CAP * sizeof(int32_t);
     if (lds > 160 * 1024) throw Error(FC_ERR_UNSUPPORTED, "knn: feature dimension too large for the LDS tile");
-    static bool attr_done = false;
-    if (!attr_done) {
-        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static PerDeviceOnce attr_once;
+    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); return 0; });
     ProfScope ps("fc::knn_kernel(float const*, int, int, int*, int, int, int)", 2.0 * B * (double)M * M * C, 4.0 * B * (double)M * (C + k), s);
     hipLaunchKernelGGL(knn_kernel, dim3((M + 15) / 16, B), dim3(256), lds, s, f, ldf, Cp, idx, M, m_stride_rows, k);
     FC_HIP(hipGetLastError());

@@ -554,17 +554,8 @@ int g_mlp_rows = 1;          // knob 23: 1 = row-resident coupling MLP chain (sh
 template <int KS0, int ACT, bool STAMPS = false>
 static void mr_launch(const MlpRowsParams& p, int rows_alloc, double flops, hipStream_t s) {
     auto kern = mlp_rows_kernel<KS0, ACT, STAMPS>;
-    static std::mutex mu;
-    static bool attr_done[16] = {};
-    int dev = 0;
-    FC_HIP(hipGetDevice(&dev));
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (dev < 16 && !attr_done[dev]) {
-            FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MR_LDS));
-            attr_done[dev] = true;
-        }
-    }
+    static PerDeviceOnce attr_once;
+    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MR_LDS)); return 0; });
     char name[96];
     snprintf(name, sizeof name, "void fc::mlp_rows_kernel<%d, %d>(fc::MlpRowsParams)", KS0, ACT);
     ProfScope ps(name, flops, 0.0, s);

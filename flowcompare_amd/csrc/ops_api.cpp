@@ -17,7 +17,7 @@ struct TmpBuf {
 }  // namespace fc
 
 
-namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; size_t gemm_read_stamps(unsigned long long*, size_t); }
+namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }
 
 extern "C" {
@@ -72,6 +72,13 @@ int fc_range_check_resolve(int32_t* n_repeated) {
     FC_API_END
 }
 int32_t fc_range_check_pending(void) { return fc::guard_pending(); }
+
+/* diagnostic: trace of every coupling's x2 input of the calling thread's next fc_flow_logprob_f32 calls into a DEVICE buffer
+   [n_flow_layers][B * N][d2] (flow_engine.cpp flow_set_trace); NULL switches it off.  Test infrastructure, not part of fcflow.h. */
+int fc_debug_flow_trace(float* device_buf, int64_t capacity_floats) {
+    fc::flow_set_trace(device_buf, device_buf && capacity_floats > 0 ? (size_t)capacity_floats : 0);
+    return FC_OK;
+}
 
 /* number of calls that were repeated with the bf16-limb GEMMs because an activation left fp16's range (tests, diagnostics) */
 int64_t fc_debug_fp16_fallbacks(void) { return (int64_t)fc::gemm_fp16_fallbacks(); }

@@ -544,11 +544,8 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
                    const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s, float* keep_ws, size_t keep_floats) {
     if (rows_alloc % PM_ROWS != 0 || ldx % 4 != 0 || ldx < in.K_pad || ((uintptr_t)x & 15))
         throw Error(FC_ERR_INVALID, "premlp: rows must be padded to 64, input pitch to 4 floats");
-    static bool attr_done = false;
-    if (!attr_done) {
-        FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(premlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PM_LDS));
-        attr_done = true;
-    }
+    static PerDeviceOnce attr_once;
+    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(premlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PM_LDS)); return 0; });
     PreMlpParams p{};
     p.x = x; p.ldx = ldx;
     auto L = [](const PackedLinear& l) { return PreMlpLayer{l.W2, l.bias, l.K_pad}; };
@@ -560,7 +557,8 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
     if (g_premlp_fused == 2 && rows_alloc % PR_ROWS == 0 && ldq % 4 == 0 && ((uintptr_t)qout & 15) == 0 && keep_ws && ((uintptr_t)keep_ws & 15) == 0 &&
         keep_floats >= (size_t)rows_alloc * PM_H) {
         auto go = [&](auto kern) {
-            FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS));
+            static PerDeviceOnce attr_once;                             // (one per kernel instantiation: `go` is a generic lambda)
+            attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS)); return 0; });
             ProfScope ps("fc::premlp_rows_kernel(fc::PreMlpParams)", flops, 0.0, s);
             hipLaunchKernelGGL(kern, dim3(rows_alloc / PR_ROWS), dim3(PR_NT), PR_LDS, s, p);
             FC_HIP(hipGetLastError());

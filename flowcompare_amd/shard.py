@@ -140,17 +140,30 @@ class GradientReducer:
     def finish(self):
         """Waits for every bucket (launching those whose parameters received no gradient this step, as zeros, so that all ranks issue
         the same collectives); afterwards every .grad view holds the sum over ranks, and parameters without a gradient on any rank have
-        .grad = None again."""
+        .grad = None again.  The presence mask is all-reduced every step (one tiny asynchronous collective, so every rank issues the same
+        sequence whatever its own pattern) but read back to the host -- the only host synchronisation of the step -- only when this
+        rank's own pattern differs from the one its cached answer belongs to: the set of gradient-less parameters is a property of the
+        graph, not of the data, so in the steady state finish() never waits for the device."""
         for i in range(len(self.buckets)):
             if self.inflight[i] is None:
                 self._launch(i)
-        mask = torch.tensor(self.present, dtype=torch.float32).to(self.flat[0].device)
-        dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+        pattern = tuple(self.present)
+        cached = getattr(self, "_mask_cache", None)
+        if cached is None or cached[0] != pattern:
+            local = torch.tensor(self.present, dtype=torch.float32).to(self.flat[0].device)
+        else:
+            local = cached[1]
+        mask = local.clone()
+        work = dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for w in self.inflight:
             w.wait()
-        mask = mask.cpu()
-        for p, m in zip(self.params, mask.tolist()):
-            if m == 0.0:
+        work.wait()
+        if cached is None or cached[0] != pattern:
+            absent = [m == 0.0 for m in mask.cpu().tolist()]
+            self._mask_cache = (pattern, local, absent)
+        self.absent = self._mask_cache[2]
+        for p, a in zip(self.params, self.absent):
+            if a:
                 p.grad = None
         self.reset()
 
@@ -163,10 +176,9 @@ class FlatAdam:
     """clip_grad_norm_ + torch.optim.Adam.step (train.py:112-120) as HIP kernels on the reducer's flat gradient buffers: the Adam moments
     mirror the bucket layout, the parameters are reached through a device pointer table, one launch per bucket (csrc/train_optim.hip)
     instead of torch's foreach kernels over ~3000 tensors.  Semantics of torch.optim.Adam(amsgrad=False): L2 weight decay added to the
-    gradient, bias corrections 1 - beta^t.  The clip coefficient min(1, max_norm / (norm + 1e-6)) stays on the device between the norm
-    and the update.  Difference to torch: a parameter whose `.grad` is None after `reducer.finish()` (no gradient on any rank) is not
-    skipped but sees the zero slice of its bucket -- its moments decay and weight decay still applies; on this path every parameter of
-    the flow and of a trained embedder receives a gradient every step."""
+    gradient, bias corrections 1 - beta^t, parameters whose `.grad` is None after `reducer.finish()` skipped.  The clip coefficient
+    min(1, max_norm / (norm + 1e-6)) stays on the device between the norm and the update.  One step counter for all parameters (torch
+    keeps one per parameter; they only differ for parameters that were skipped in some steps)."""
 
     def __init__(self, reducer, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         import ctypes
@@ -179,26 +191,44 @@ class FlatAdam:
             raise RuntimeError("FlatAdam: fp32 parameters on a HIP device (there is no CPU path)")
         self.m = [torch.zeros_like(f) for f in reducer.flat]
         self.v = [torch.zeros_like(f) for f in reducer.flat]
-        self.tables = []
-        chunk = 4096
         for b in reducer.buckets:
             for p in b:
                 if not p.is_contiguous():
                     raise RuntimeError("FlatAdam: parameters must be contiguous")
-            ptrs = torch.tensor([p.data_ptr() for p in b], dtype=torch.int64, device=dev)
-            sizes = [p.numel() for p in b]
-            offs = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0).tolist()), dtype=torch.int64, device=dev)
-            ct, co = [], []
-            for i, n in enumerate(sizes):
-                for o in range(0, n, chunk):
-                    ct.append(i)
-                    co.append(o)
-            self.tables.append((ptrs, offs, torch.tensor(ct, dtype=torch.int32, device=dev), torch.tensor(co, dtype=torch.int64, device=dev), len(ct)))
+        self.tables, self._table_key = None, None
         L = engine.lib()
         nb = max(L.fc_train_sqnorm_ws_bytes(ctypes.c_int64(f.numel())) for f in reducer.flat)
         self.ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         self.sq = torch.zeros(len(reducer.flat), dtype=torch.float64, device=dev)
         self.coef = torch.ones(1, dtype=torch.float32, device=dev)
+
+    def _tables(self):
+        """Device tables of the update kernel: parameter addresses, their offsets in the bucket and the 4096-element chunks to visit.
+        Re-built when a parameter's storage moved (module.to(), a re-created Parameter whose tensor the caller swapped in place of the old
+        one's `.data`) or when the set of parameters without a gradient changed: those are left out of the chunk list, so -- like
+        torch.optim.Adam, which skips `p.grad is None` -- they see neither weight decay nor moment decay."""
+        r = self.reducer
+        absent = getattr(r, "absent", None) or [False] * len(r.params)
+        key = (tuple(p.data_ptr() for p in r.params), tuple(absent))
+        if key == self._table_key:
+            return self.tables
+        dev = r.flat[0].device
+        chunk = 4096
+        tables = []
+        for b in r.buckets:
+            ptrs = torch.tensor([p.data_ptr() for p in b], dtype=torch.int64, device=dev)
+            sizes = [p.numel() for p in b]
+            offs = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0).tolist()), dtype=torch.int64, device=dev)
+            ct, co = [], []
+            for i, (p, n) in enumerate(zip(b, sizes)):
+                if absent[r.index_of[id(p)]]:
+                    continue
+                for o in range(0, n, chunk):
+                    ct.append(i)
+                    co.append(o)
+            tables.append((ptrs, offs, torch.tensor(ct or [0], dtype=torch.int32, device=dev), torch.tensor(co or [0], dtype=torch.int64, device=dev), len(ct)))
+        self.tables, self._table_key = tables, key
+        return tables
 
     def step(self, max_norm=None):
         """Global-norm clip (optional) + Adam update; returns the gradient norm (device scalar, before clipping)."""
@@ -216,8 +246,11 @@ class FlatAdam:
             norm = self.sq.sum().sqrt()                                           # parameter-sized: 39 numbers
             if max_norm:
                 self.coef.copy_((max_norm / (norm + 1e-6)).clamp(max=1.0).to(torch.float32).reshape(1))
+            tables = self._tables()
             for i, f in enumerate(r.flat):
-                ptrs, offs, ct, co, n_chunks = self.tables[i]
+                ptrs, offs, ct, co, n_chunks = tables[i]
+                if n_chunks == 0:
+                    continue
                 engine._check(L.fc_train_adam_f32(engine._ptr(ptrs), engine._ptr(offs), engine._ptr(ct), engine._ptr(co), n_chunks, engine._ptr(f),
                                                   engine._ptr(self.m[i]), engine._ptr(self.v[i]), engine._ptr(self.coef) if max_norm else ctypes.c_void_p(0),
                                                   ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]), ctypes.c_float(self.betas[1]),
@@ -238,20 +271,60 @@ class FlatAdam:
                                                   "params": list(range(len(self.reducer.params)))}]}
 
 
+    def load_state_dict(self, sd):
+        """Restores what state_dict() / torch.optim.Adam.state_dict() wrote (load_flow's optimizer entry, model_initialization.py:18-28):
+        moments into the flat buffers, the step counter, the hyper-parameters of the (single) parameter group."""
+        r = self.reducer
+        state = sd["state"]
+        steps = []
+        for j, p in enumerate(r.params):
+            st = state.get(j, state.get(str(j)))
+            if st is None:
+                continue                                    # torch leaves parameters that never received a gradient without state
+            i = r.bucket_of[id(p)]
+            off = (r.views[id(p)].data_ptr() - r.flat[i].data_ptr()) // 4
+            n = p.numel()
+            if st["exp_avg"].numel() != n or st["exp_avg_sq"].numel() != n:
+                raise RuntimeError(f"FlatAdam.load_state_dict: parameter {j} has {n} elements, the checkpoint {st['exp_avg'].numel()}")
+            self.m[i][off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[i][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.append(int(float(st["step"])))
+        self.t = max(steps) if steps else 0
+        groups = sd.get("param_groups") or []
+        if groups:
+            g = groups[0]
+            self.lr, self.betas = float(g.get("lr", self.lr)), tuple(float(b) for b in g.get("betas", self.betas))
+            self.eps, self.weight_decay = float(g.get("eps", self.eps)), float(g.get("weight_decay", self.weight_decay))
+
+
 def sync_batchnorm_buffers(module, group=None):
     """Train-mode BatchNorm running statistics are per shard, as in the reference's nn.DataParallel (no SyncBN): every
-    rank updates them from its own scenes.  Averaging them over the ranks after a step keeps the replicas' eval-mode behaviour and
-    checkpoints identical (a conscious deviation: DataParallel keeps replica 0's).  Parameter-sized; one all-reduce."""
-    bufs = [b for n, b in module.named_buffers() if n.endswith(("running_mean", "running_var")) and b.is_floating_point()]
-    if not bufs or dist.get_world_size(group) == 1:
+    rank updates them from its own scenes.  Combining them over the ranks after a step keeps the replicas' eval-mode behaviour and
+    checkpoints identical (a conscious deviation: DataParallel keeps replica 0's): the mean is the average of the ranks' means and the
+    variance is E[var + mean^2] - mean^2 over the ranks, i.e. it includes the spread of the ranks' means (the same combination
+    _actnorm_data_init uses).  Parameter-sized; one all-reduce.  Nothing to do in eval mode (the buffers did not move) or with one rank."""
+    if not module.training or dist.get_world_size(group) == 1:
         return
-    flat = torch.cat([b.reshape(-1).to(torch.float32) for b in bufs])
+    stats = dict(module.named_buffers())
+    pairs = [(stats[n], stats[n[: -len("running_mean")] + "running_var"]) for n in stats
+             if n.endswith("running_mean") and stats[n].is_floating_point() and n[: -len("running_mean")] + "running_var" in stats]
+    seen, uniq = set(), []
+    for m, v in pairs:                                       # the embedders register the same BatchNorm under two names (bn1 = conv1.1)
+        if m.data_ptr() not in seen:
+            seen.add(m.data_ptr())
+            uniq.append((m, v))
+    if not uniq:
+        return
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for m, v in uniq for t in (m, v + m * m)])
     dist.all_reduce(flat, group=group)
     flat /= dist.get_world_size(group)
     off = 0
-    for b in bufs:
-        b.copy_(flat[off:off + b.numel()].view_as(b))
-        off += b.numel()
+    for m, v in uniq:
+        n = m.numel()
+        mean, second = flat[off:off + n].view_as(m), flat[off + n:off + 2 * n].view_as(v)
+        m.copy_(mean)
+        v.copy_((second - mean * mean).clamp_min(0))
+        off += 2 * n
 
 
 def local_loss(log_prob_local, n_global_points):

@@ -20,6 +20,7 @@ checkpoint, the HIP engine and this oracle all consume the same weights.
 Every function cites the reference file:line it restates
 (paths relative to the reference repository root).
 """
+import contextlib
 import math
 
 import torch
@@ -100,6 +101,33 @@ def affine_coupling(sd, prefix, x, cond, act, scale_fn, split=None, inverse=Fals
     return torch.cat((a, b * s + t), -1), torch.log(s).sum(-1)
 
 
+_SPLINE_HOOK = None      # test helper of the full-depth parity tests: spline_decisions() below
+
+
+@contextlib.contextmanager
+def spline_decisions(forced=None):
+    """Test helper (tests/fullsize_util.py).  Records the inside / outside decision `-3 <= x2 <= 3` (models/spline_coupling.py:35-48) of every
+    forward spline evaluation inside the block, in call order (one [..., d2] bool mask per coupling layer), into the yielded list; with
+    `forced` (a list of such masks, e.g. the decisions a HIP run took on its own fp32 latent) the evaluation uses THOSE decisions instead
+    of its own: a forced-inside input that sits a rounding error beyond the boundary is evaluated at the boundary knot, a forced-outside
+    one passes through with log-det 0.  The spline has derivative 0.6936 at the boundary knots but the identity outside, so log p jumps by
+    0.366 nats at |x2| = 3: an fp32 run may land on either side where its latent is within its rounding error of 3, and only the run's
+    own decisions make a like-for-like fp64 reference for it."""
+    global _SPLINE_HOOK
+    rec, it = [], (iter(forced) if forced is not None else None)
+
+    def hook(x, inside):
+        if it is not None:
+            inside = next(it).to(torch.bool).reshape(inside.shape)
+        rec.append(inside)
+        return inside
+    prev, _SPLINE_HOOK = _SPLINE_HOOK, hook
+    try:
+        yield rec
+    finally:
+        _SPLINE_HOOK = prev
+
+
 def rq_spline(x, uw, uh, ud, inverse=False, bound=3.0, min_w=1e-3, min_h=1e-3, min_d=1e-3):
     """models/spline_coupling.py:24-66 + :69-169 + :17-19, elementwise over x[...]
     with uw,uh [...,K] and ud [...,K+1].
@@ -112,7 +140,9 @@ def rq_spline(x, uw, uh, ud, inverse=False, bound=3.0, min_w=1e-3, min_h=1e-3, m
     """
     K = uw.shape[-1]
     inside = (x >= -bound) & (x <= bound)
-    xc = torch.where(inside, x, torch.zeros_like(x))          # any in-range stand-in for masked lanes
+    if _SPLINE_HOOK is not None and not inverse:
+        inside = _SPLINE_HOOK(x, inside)                      # (test helper: record / force the decisions; a no-op clamp otherwise)
+    xc = torch.where(inside, x.clamp(-bound, bound), torch.zeros_like(x))          # any in-range stand-in for masked lanes
     const = float(torch.tensor(math.log(math.exp((1 - min_d) - 1))))      # the reference builds it as a float32 tensor (:43)
     ud_p = torch.cat((torch.full_like(ud[..., :1], const), ud), -1)      # knots 0..K+1 (last unused)
     d = min_d + F.softplus(ud_p)

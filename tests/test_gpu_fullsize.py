@@ -18,7 +18,8 @@ import torch
 
 import flowcompare_amd as fa
 from oracle import flow_oracle as O
-from fullsize_util import build_conditioned, check_rows_against_fp64, oracle_flow_rows, state_dicts, synth_pairs
+from fullsize_util import (build_conditioned, check_spline_rows_against_fp64, hip_rows_with_decisions, oracle_flow_rows_forced, state_dicts,
+                           synth_pairs)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -46,18 +47,51 @@ def test_full_size_determinism_and_scene_independence(c2):
 
 def test_full_size_rows_match_fp64_oracle_at_golden_gates(c2):
     """Target points do not interact (each attends to the context only), so the oracle on the first 512 target points of scene 0
-    against the FULL 4096-point context checks those rows of the 16-scene, 115-layer run -- at the tolerance north_star states:
-    bpd within 1e-4 of the fp64 oracle, every row within 2e-3 (rows on the spline's +-3 boundary: near-tie rule, fullsize_util).
-    The oracle's own fp32-vs-fp64 gap on the same rows is printed beside it."""
+    against the FULL 4096-point context checks those rows of the 16-scene, 115-layer run -- at the tolerance north_star states, on
+    EVERY row: bpd within 1e-4 (mean nats within 4.2e-4) of the fp64 oracle, every row within 2e-3 or the reference arithmetic's own gap.
+    The spline's inside / outside decisions |x2| <= 3 (a 0.366-nat jump of log p, models/spline_coupling.py:35-48) are read from the HIP
+    run (engine trace of the x2 the coupling kernels read) and forced on the fp64 oracle, so rows whose fp32 latent lands on the other
+    side of the boundary than the fp64 latent are ordinary rows; the oracle's fp32 run is judged the same way against ITS decisions."""
     cfg, md, e0, e1, eps = c2
     n = 512
     _, lp, _ = fa.inner_loop((e0.to(DEV), e1.to(DEV), None), md, cfg, eps=[eps.to(DEV)])
-    ctx = md["input_embedder"](e0[:1].to(DEV)).cpu()
+    ctx_dev = md["input_embedder"](e0[:1].to(DEV))
+    lp_rows, dec_hip = hip_rows_with_decisions(cfg, md, ctx_dev, e1[:1, :n], None, [eps[:1, :n]])
+    assert torch.equal(lp_rows, lp[0, :n].cpu()), "rows of a 512-row run differ from the same rows of the 16-scene run"
+    ctx = ctx_dev.cpu()
     t0 = time.time()
-    lp64, margin = oracle_flow_rows(cfg, md, ctx, e1[:1, :n], None, [eps[:1, :n]], torch.float64)
-    lp32, _ = oracle_flow_rows(cfg, md, ctx, e1[:1, :n], None, [eps[:1, :n]], torch.float32)
+    args = (cfg, md, ctx, e1[:1, :n], None, [eps[:1, :n]])
+    lp64_nat, dec64 = oracle_flow_rows_forced(*args, torch.float64)
+    lp64_hip, _ = oracle_flow_rows_forced(*args, torch.float64, forced=dec_hip)
+    lp32, dec32 = oracle_flow_rows_forced(*args, torch.float32)
+    lp64_ref, _ = oracle_flow_rows_forced(*args, torch.float64, forced=dec32)
     print(f"oracle: {time.time() - t0:.0f} s of host time")
-    check_rows_against_fp64("C2 16 x 4096 x 115 spline layers, scene 0 rows 0..511", lp[0, :n].cpu(), lp64, lp32, margin)
+    check_spline_rows_against_fp64("C2 16 x 4096 x 115 spline layers, scene 0 rows 0..511", lp_rows, dec_hip, lp64_hip, lp64_nat, dec64, lp32, lp64_ref)
+
+
+def test_full_size_rows_match_the_oracle_end_to_end_with_its_own_embedder(c2):
+    """The same rows END TO END: HIP embedder + HIP flow against the oracle's OWN fp64 context embedding + fp64 flow (HIP spline decisions
+    forced, as above).  k-NN near-ties flip single neighbours of single context points (test_full_size_embedder...: a handful of the
+    4096 embedding rows move by up to a few 1e-3); a target row sees them through a softmax over all 4096 keys, so every row stays gated."""
+    cfg, md, e0, e1, eps = c2
+    n = 256
+    ctx_dev = md["input_embedder"](e0[:1].to(DEV))
+    lp_rows, dec_hip = hip_rows_with_decisions(cfg, md, ctx_dev, e1[:1, :n], None, [eps[:1, :n]])
+    _, sd_e = state_dicts(md, torch.float64)
+    t0 = time.time()
+    with torch.no_grad():
+        ctx64 = O.context_embed(cfg, sd_e, e0[:1].double())
+    moved = (ctx_dev.cpu().double() - ctx64).abs().amax(-1)[0]
+    print(f"context rows whose embedding differs from the fp64 oracle's by more than 1e-4 (k-NN near-ties): {int((moved > 1e-4).sum())} of {moved.numel()}")
+    lp64_nat, dec64 = oracle_flow_rows_forced(cfg, md, ctx64, e1[:1, :n], None, [eps[:1, :n]], torch.float64)
+    lp64_hip, _ = oracle_flow_rows_forced(cfg, md, ctx64, e1[:1, :n], None, [eps[:1, :n]], torch.float64, forced=dec_hip)
+    _, se32 = state_dicts(md, torch.float32)
+    with torch.no_grad():
+        ctx32 = O.context_embed(cfg, se32, e0[:1])
+    lp32, dec32 = oracle_flow_rows_forced(cfg, md, ctx32, e1[:1, :n], None, [eps[:1, :n]], torch.float32)
+    lp64_ref, _ = oracle_flow_rows_forced(cfg, md, ctx64, e1[:1, :n], None, [eps[:1, :n]], torch.float64, forced=dec32)
+    print(f"oracle: {time.time() - t0:.0f} s of host time")
+    check_spline_rows_against_fp64("C2 end to end (oracle's own fp64 embedder), scene 0 rows 0..255", lp_rows, dec_hip, lp64_hip, lp64_nat, dec64, lp32, lp64_ref)
 
 
 def test_full_size_embedder_matches_fp64_oracle(c2):

@@ -765,6 +765,41 @@ def _flat_adam_worker(rank, world, port, q):
         sd = opt.state_dict()
         tsd = topt.state_dict()
         merr = max(float((sd["state"][j]["exp_avg"] - tsd["state"][j]["exp_avg"]).abs().max()) for j in range(len(ps)))
+        # a resumed run: a fresh FlatAdam restored from torch's checkpoint layout (load_flow's optimizer entry), then one step in which
+        # parameter 2 has no gradient on any rank -- torch.optim.Adam skips it (no weight decay, no moment decay), and so must the kernel
+        opt2 = shard.FlatAdam(reducer, lr=1.0)
+        opt2.load_state_dict(tsd)
+        assert opt2.t == 4 and opt2.lr == 3e-3 and opt2.weight_decay == 0.01
+        # (i) a parameter whose storage was replaced (module.to(), a re-created Parameter): the pointer table follows it
+        ps[0].data = ps[0].data.clone()
+        ref0 = ref[0].detach().clone()
+        reducer.zero_grad()
+        for p, r in zip(ps, ref):
+            g = torch.randn(p.shape, device=DEV) * 0.1
+            p.grad.copy_(g)
+            r.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ref, max_norm=1.0)
+        topt.step()
+        opt2.step(max_norm=1.0)
+        assert not torch.equal(ref[0].detach(), ref0)
+        err = max(err, max(float((p.detach() - r.detach()).abs().max()) for p, r in zip(ps, ref)))
+        # (ii) parameter 2 without a gradient (last: FlatAdam keeps ONE step counter, torch one per parameter, so a skipped parameter's
+        # bias corrections would differ from torch's in any later step that updates it again)
+        reducer.zero_grad()
+        gs = [torch.randn(s, device=DEV) * 0.1 for s in shapes]
+        for j, (p, r, g) in enumerate(zip(ps, ref, gs)):
+            if j == 2:
+                p.grad, r.grad = None, None
+                continue
+            p.grad.copy_(g)
+            r.grad = g.clone()
+        reducer.absent = [j == 2 for j in range(len(ps))]
+        before = ps[2].detach().clone()
+        torch.nn.utils.clip_grad_norm_([r for r in ref if r.grad is not None], max_norm=1.0)
+        topt.step()
+        opt2.step(max_norm=1.0)
+        assert torch.equal(ps[2].detach(), before), "a parameter without a gradient must be skipped"
+        err = max(err, max(float((p.detach() - r.detach()).abs().max()) for p, r in zip(ps, ref)))
         q.put((rank, err, worst_n, merr))
     finally:
         dist.destroy_process_group()
@@ -772,9 +807,11 @@ def _flat_adam_worker(rank, world, port, q):
 
 def test_flat_adam_matches_torch_adam_with_clipping():
     """The native optimiser step (global-norm clip + Adam on the reducer's flat buffers, csrc/train_optim.hip) against
-    torch.nn.utils.clip_grad_norm_ + torch.optim.Adam over four steps, one of them clipped hard; moments exported in torch's layout."""
+    torch.nn.utils.clip_grad_norm_ + torch.optim.Adam over four steps, one of them clipped hard; moments exported in torch's layout;
+    then a fresh FlatAdam restored with load_state_dict, a step with a gradient-less parameter (skipped like torch skips it) and a step
+    after a parameter's storage moved."""
     res, codes = _spawn(_flat_adam_worker, 1)
     assert codes == [0]
     _, err, worst_n, merr = res[0]
-    print(f"FlatAdam vs torch Adam after 4 steps: max |dp| {err:.2e}, gradient norm rel. error {worst_n:.1e}, exp_avg max diff {merr:.1e}")
+    print(f"FlatAdam vs torch Adam after 4 + 2 steps (resumed): max |dp| {err:.2e}, gradient norm rel. error {worst_n:.1e}, exp_avg max diff {merr:.1e}")
     assert err < 2e-6 and worst_n < 1e-6 and merr < 1e-7

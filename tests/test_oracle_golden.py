@@ -136,3 +136,31 @@ def test_pointops_restatements_basic_properties():
     assert (nn_small[..., 5:] == 0).all()                                                    # unfilled heap slots keep index 0
     dist, i3 = P.nearest_neighbor3(xyz, xyz[:, :1])
     assert torch.isinf(dist[..., 1:]).all() and (i3 == 0).all()                              # fewer than 3 known points
+
+
+def test_spline_decision_hook_records_and_forces_without_changing_the_natural_run():
+    """oracle.spline_decisions (full-depth parity helper): recording changes nothing; forcing a run's own decisions reproduces it bit for
+    bit; forcing an input just beyond the boundary inside evaluates it at the boundary knot (at -3: derivative 0.6936 -> log-det -0.366), and
+    forcing one just inside the boundary outside passes it through with log-det 0."""
+    import math
+    from oracle import flow_oracle as O
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 7, generator=g, dtype=torch.float64) * 2.5
+    uw, uh, ud = (torch.randn(4, 7, n, generator=g, dtype=torch.float64) for n in (8, 8, 9))
+    y0, l0 = O.rq_spline(x, uw, uh, ud)
+    with O.spline_decisions() as rec:
+        y1, l1 = O.rq_spline(x, uw, uh, ud)
+    assert torch.equal(y0, y1) and torch.equal(l0, l1) and len(rec) == 1 and rec[0].dtype == torch.bool
+    assert torch.equal(rec[0], (x >= -3) & (x <= 3)) and (~rec[0]).any() and rec[0].any()
+    with O.spline_decisions(forced=rec) as rec2:
+        y2, l2 = O.rq_spline(x, uw, uh, ud)
+    assert torch.equal(y0, y2) and torch.equal(l0, l2) and torch.equal(rec2[0], rec[0])
+    xb = torch.tensor([[3.0 + 1e-7, 3.0 - 1e-7, -3.0 - 1e-7]], dtype=torch.float64)
+    p = [torch.randn(1, 3, n, generator=g, dtype=torch.float64) for n in (8, 8, 9)]
+    with O.spline_decisions(forced=[torch.tensor([[True, False, True]])]):
+        yb, lb = O.rq_spline(xb, *p)
+    jump = math.log(math.log1p(math.exp(-1e-3)) + 1e-3)
+    # (the reference's derivative padding makes only knot 0 the constant: the upper boundary knot carries the last learned derivative)
+    assert abs(float(yb[0, 0]) - 3.0) < 1e-9 and math.isfinite(float(lb[0, 0]))
+    assert float(yb[0, 1]) == float(xb[0, 1]) and float(lb[0, 1]) == 0.0
+    assert abs(float(yb[0, 2]) + 3.0) < 1e-9 and abs(float(lb[0, 2]) - jump) < 1e-6

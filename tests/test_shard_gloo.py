@@ -142,3 +142,46 @@ def test_two_rank_sharded_backward_reproduces_the_reference_full_batch_gradients
             assert np.abs(got - want[:3]).max() < 1e-8 * max(want[1], 1e-9 * float(z["eval/grad_norm"])) + 1e-12, (rank, key)
     for k in res[0][2]:
         assert np.array_equal(res[0][2][k], res[1][2][k])      # both ranks hold identical reduced gradients
+
+
+def _bn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bn = torch.nn.BatchNorm1d(3)
+        holder = torch.nn.Module()
+        holder.bn1 = bn
+        holder.alias = torch.nn.Sequential(bn)               # the embedders register every BatchNorm under two names
+        with torch.no_grad():
+            bn.running_mean.copy_(torch.tensor([1.0, -2.0, 0.5]) * (rank + 1))
+            bn.running_var.copy_(torch.tensor([0.5, 1.0, 2.0]) + rank)
+        holder.eval()
+        before = bn.running_mean.clone()
+        shard.sync_batchnorm_buffers(holder)                 # eval mode: the buffers did not move, nothing is exchanged
+        assert torch.equal(bn.running_mean, before)
+        holder.train()
+        shard.sync_batchnorm_buffers(holder)
+        q.put((rank, bn.running_mean.clone().numpy(), bn.running_var.clone().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_batchnorm_running_statistics_combine_as_one_population():
+    """sync_batchnorm_buffers: mean of the ranks' means; variance E[var + mean^2] - mean^2, i.e. the spread of the ranks' means counts."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=100) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    m = [torch.tensor([1.0, -2.0, 0.5]) * (r + 1) for r in range(2)]
+    v = [torch.tensor([0.5, 1.0, 2.0]) + r for r in range(2)]
+    mean = (m[0] + m[1]) / 2
+    var = (v[0] + m[0] ** 2 + v[1] + m[1] ** 2) / 2 - mean ** 2
+    for _, rm, rv in res:
+        assert torch.allclose(torch.from_numpy(rm), mean, atol=1e-6) and torch.allclose(torch.from_numpy(rv), var, atol=1e-6)
