@@ -8,7 +8,7 @@ namespace fc {
 
 // Exact (erf) GELU in one branch-free chain: gelu(v) = v Phi(v), Phi(-|v|) = erfc(u)/2 with u = |v|/sqrt(2), and
 // log2 erfc(u) = -u^2 log2(e) + log2 erfcx(u), where log2 erfcx is smooth and slowly varying (0 ... -3.3 on [0, 5.2]) and is fitted
-// by a degree-11 polynomial (Chebyshev fit, profiles/micro/fit_gelu.py).  22 VALU instructions instead of the 28 of the two-branch erf fit it replaced -- the GEMM epilogues and the fused pre-attention kernel are VALU-bound (PMC: 8-12 VALU instructions per MFMA).
+// by a degree-11 polynomial (Chebyshev fit, profiles/micro/fit_gelu.py).  20 VALU instructions instead of the 28 of the two-branch erf fit it replaced -- the GEMM epilogues and the fused pre-attention kernel are VALU-bound (PMC: 8-12 VALU instructions per MFMA).
 // fp32 accuracy against fp64: |error| <= 2.4e-7 (half an ulp of v at |v| ~ 5), 9.8e-8 relative to max(1, |v|), and 5e-6 RELATIVE
 // in the negative tail, where the two-branch form lost all relative accuracy (1 - (1 - e^q)).
 __device__ __forceinline__ float fc_gelu(float v) {
@@ -24,10 +24,52 @@ __device__ __forceinline__ float fc_gelu(float v) {
     g = fmaf(g, u, -0.14908140897750854f);
     g = fmaf(g, u, 0.5244691371917725f);
     g = fmaf(g, u, -1.627930760383606f);
-    g = fmaf(g, u, 4.18458824924528e-07f);
-    const float e = __builtin_amdgcn_exp2f(fmaf(-1.4426950408889634f * u, u, g));      // erfc(u)
-    const float h = (0.5f * v) * e;                                                   // v Phi(-|v|), signed like v
-    return v > 0.f ? v - h : h;
+    g = fmaf(g, u, 4.18458824924528e-07f - 1.0f);                                    // (- 1: the 1/2 of Phi(-|v|) = erfc(u) / 2 in the log2 domain)
+    const float e = __builtin_amdgcn_exp2f(fmaf(-1.4426950408889634f * u, u, g));      // erfc(u) / 2
+    const float h = v * e;                                                            // v Phi(-|v|), signed like v
+    return fmaxf(v, 0.f) - fabsf(h);                                                   // = v > 0 ? v - h : h (up to the sign of a zero), without compare + select
+}
+
+// Two values -> their packed fp16 limb words: hi = [rn16(x0) | rn16(x1) << 16], lo = [rn16((x0 - hi0) * 2048) |
+// rn16((x1 - hi1) * 2048) << 16].  Five VALU instructions for the pair -- v_cvt_pk_f16_f32, two v_fma_mix_f32 that subtract the fp16 halves
+// from the fp32 inputs (exact), v_fma_mixlo / mixhi_f16 for the scaled remainders -- where the scalar formulation compiles to ten (convert,
+// convert back, subtract, multiply-convert, pack, per value).  Same roundings, same bits.  The limb splits sit in VALU-bound epilogues
+// (attention's P, the row-resident MLP kernels): round 3.
+__device__ __forceinline__ void limb_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    float d0, d1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hi), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(lo) : "v"(d0), "s"(2048.0f));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(lo) : "v"(d1), "s"(2048.0f));
+}
+// element SEL (0 = low half, 1 = high half) of packed limb words back to fp32, x = hi + lo'/2048, in one v_fma_mix_f32 (the scalar
+// formulation is two converts and a multiply-add); the product is exact, the sum rounds once either way: same bits
+template <int SEL>
+__device__ __forceinline__ float limb_join(unsigned hi, unsigned lo) {
+    float r;
+    if constexpr (SEL == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(lo), "s"(1.0f / 2048.0f), "v"(hi));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(lo), "s"(1.0f / 2048.0f), "v"(hi));
+    return r;
+}
+// eight values -> one MFMA operand fragment per limb
+typedef _Float16 fc_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned fc_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void limb_split8(const float (&x)[8], fc_f16x8& hi, fc_f16x8& lo) {
+    fc_u32x4 h, l;
+    unsigned a, b;
+    limb_split2(x[0], x[1], a, b); h[0] = a; l[0] = b;
+    limb_split2(x[2], x[3], a, b); h[1] = a; l[1] = b;
+    limb_split2(x[4], x[5], a, b); h[2] = a; l[2] = b;
+    limb_split2(x[6], x[7], a, b); h[3] = a; l[3] = b;
+    hi = __builtin_bit_cast(fc_f16x8, h);
+    lo = __builtin_bit_cast(fc_f16x8, l);
+}
+// and back: one fragment per limb -> eight values
+__device__ __forceinline__ void limb_join8(const fc_f16x8& hi, const fc_f16x8& lo, float (&x)[8]) {
+    const fc_u32x4 h = __builtin_bit_cast(fc_u32x4, hi), l = __builtin_bit_cast(fc_u32x4, lo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[2 * i] = limb_join<0>(h[i], l[i]); x[2 * i + 1] = limb_join<1>(h[i], l[i]); }
 }
 
 __device__ __forceinline__ float act_apply(float v, int act) {

@@ -14,6 +14,7 @@
 //     (r&3)+8(r>>2)+4h of step r), with B = V[key][d] read row-wise from LDS (conflict-free ds_read_b32).
 // No LDS round trip for P, no transposed V image.
 #include "common.h"
+#include "activations.h"
 #include <cstdio>
 
 namespace fc {
@@ -402,11 +403,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 f16x8 ph, pl;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float x = s[h2][8 * s2 + j];
-                    ph[j] = (_Float16)x;
-                    pl[j] = (_Float16)((x - (float)ph[j]) * 2048.0f);
+                {
+                    const float x8[8] = {s[h2][8 * s2], s[h2][8 * s2 + 1], s[h2][8 * s2 + 2], s[h2][8 * s2 + 3],
+                                         s[h2][8 * s2 + 4], s[h2][8 * s2 + 5], s[h2][8 * s2 + 6], s[h2][8 * s2 + 7]};
+                    limb_split8(x8, ph, pl);                     // (5 VALU per pair of probabilities: this kernel is VALU-bound on exactly this)
                 }
                 const char* vr = sV + (32 * h2 + 16 * s2) * VP + tr_off;
 #pragma unroll

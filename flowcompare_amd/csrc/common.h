@@ -249,6 +249,7 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
 size_t mlp_rows_image_bytes(int K_pad);
 void launch_mlp_rows_image(const PackedLinear& L, unsigned short* Wf, hipStream_t s);      // fills L's fragment-major image from L.W2
 bool mlp_rows_eligible(const PackedLinear& in, const std::vector<PackedLinear>& mid, int act);
+bool mlp_rows_fills_the_chip(int rows_alloc);           // at least 3/4 of the CUs get a 128-row workgroup
 void launch_mlp_rows(const PackedLinear& in, const std::vector<PackedLinear>& mid, const ASeg* segs, const float* rowscal, int act,
                      float* const h[3], unsigned short* out16, int rows_alloc, int rows_valid, hipStream_t s);
 void launch_limb_decode(const unsigned short* img, float* out, int ldo, int rows, int width, hipStream_t s);   // row-major limb image -> fp32 (tests)

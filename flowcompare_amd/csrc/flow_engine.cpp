@@ -565,7 +565,9 @@ static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_s
                           unsigned short* last_limbs = nullptr) {
     // 512-wide coupling nets inside a guard scope: in_layer + hidden layers as ONE row-resident launch (mlprows.hip); the scratch images
     // of its intermediate activations live in the h[] buffers (same 2 KB per row as a 512-wide fp32 panel)
-    if (last_limbs && f.d.H_pad == 512 && gemm_limb_chain_all_ok() && mlp_rows_eligible(m.in_layer, m.mid, act)) {
+    // (a workgroup owns 128 rows for the whole chain: with fewer workgroups than ~3/4 of the CUs -- C1's 2 x 1024 points are 16 -- the chain
+    // of ONE workgroup is the launch's duration and the per-layer launches on 64 x 64 tiles are faster: 21 vs 38 ms per C1 step)
+    if (last_limbs && f.d.H_pad == 512 && gemm_limb_chain_all_ok() && mlp_rows_eligible(m.in_layer, m.mid, act) && mlp_rows_fills_the_chip(w.P_pad)) {
         launch_mlp_rows(m.in_layer, m.mid, in_segs, rowscal, act, w.h, last_limbs, w.P_pad, w.P, s);
         return -1;
     }

@@ -190,30 +190,9 @@ void gemm_f32_kernel(const GemmParams p) {
                     for (int r = 0; r < 16; ++r) acc[i][j][r] += rs[i][r] * cv;
             }
         }
-        if (e.residual16) {
-            // residual from the limb image its producer wrote (hidden activations of a limb-chained MLP exist only in that form)
-            const int blocks = e.ldr16 >> 4;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (j < nvalid) {
-                    const int col = wave_n0 + j * 32 + li;
-                    const unsigned short* rp = e.residual16 + ((size_t)(wave_m0 + 4 * lh) * blocks + (col >> 4)) * 32 + (col & 15);
-                    unsigned short th[TM][16], tl[TM][16];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const unsigned short* q = rp + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * blocks * 32;
-                            th[i][r] = q[0]; tl[i][r] = q[16];
-                        }
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            acc[i][j][r] += (float)__builtin_bit_cast(_Float16, th[i][r]) + (float)__builtin_bit_cast(_Float16, tl[i][r]) * (1.0f / 2048.0f);
-                }
-            }
-        }
+        // (a residual that arrives as a limb image, e.residual16, is added BEHIND the k loop -- in the epilogue below: the row-resident chain
+        // kernel (mlprows.hip) adds it there, and the engine picks between that kernel and these per-layer launches by the row count, so the
+        // two must round alike for a scene's log-probs not to depend on the batch it sits in; it is also the more accurate order)
         if (e.residual) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -258,7 +237,10 @@ void gemm_f32_kernel(const GemmParams p) {
                           (VAR == 9 && BM == 64 && BN == 64 && WM == 2 && ((WN == 2 && EPI == EPI_LINEAR) || (WN == 1 && EPI == EPI_AFFINE))),
                       "LDS-DMA loop: 256x128 on 4x2 waves (VAR 8), 128x128 on 2x2 waves (VAR 9) or on 4x1 waves, transposed (VAR 10); 64x64 on 2x2 "
                       "waves (EPI_LINEAR) / 2x1 waves (EPI_AFFINE: a wave's 64 columns are one pair block) for launches too small to fill the chip with 128x128 tiles");
-        constexpr int NST8 = VAR == 8 ? 3 : 2;
+        // 64 x 64 tiles (launches too small to fill the chip: ONE workgroup's k loop is the launch's duration, and with 6 MFMAs per wave and
+        // k step that loop is pure DMA latency): EIGHT stages of 16 KB, seven k steps in flight, so the whole K = 512 operand is on its way
+        // after one latency instead of one latency per k step (C1: 19 -> ~10 us per hidden-layer launch).  Same MFMAs in the same order.
+        constexpr int NST8 = VAR == 8 ? 3 : (BM == 64 ? 8 : 2);
         constexpr int ROWB8 = 128, STAGE8 = (BM + BN) * ROWB8;        // launch_cfg reserves NST8 * STAGE8
         constexpr int PPW = STAGE8 / 1024 / (NT / 64);                       // 1-KB DMA pieces per wave and stage: 6
         typedef __attribute__((address_space(3))) char lds_char;
@@ -317,7 +299,22 @@ void gemm_f32_kernel(const GemmParams p) {
                     }                                                                                              \
             }                                                                                                      \
         }
-        if constexpr (NST8 == 3) {
+        if constexpr (NST8 > 3) {
+            constexpr int DEPTH = NST8 - 1;
+            static_assert((DEPTH - 1) * PPW <= 63, "counted vmcnt wait");
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) FC_DMA8((d < KT ? d : KT - 1), d)
+            int st = 0;
+            for (int kt = 0; kt < KT; ++kt) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PPW) : "memory");   // this wave's pieces of tile kt have landed (DEPTH - 1 younger tiles may fly on)
+                __builtin_amdgcn_s_barrier();                                   // ... and everybody's; everybody is done reading tile kt-1
+                const int kn = kt + DEPTH < KT ? kt + DEPTH : KT - 1;           // (tail: harmless re-loads into the stage tile kt-1 just left)
+                const int sn = st == 0 ? NST8 - 1 : st - 1;                     // (kt + DEPTH) % NST8
+                FC_DMA8(kn, sn)
+                FC_MMA8_STAGE(st)
+                st = st == NST8 - 1 ? 0 : st + 1;
+            }
+        } else if constexpr (NST8 == 3) {
             FC_DMA8(0, 0)
             FC_DMA8((1 < KT ? 1 : KT - 1), 1)
             int st = 0;
@@ -657,6 +654,31 @@ void gemm_f32_kernel(const GemmParams p) {
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15
     if constexpr (EPI == EPI_LINEAR) {
         if ((VAR == 8 || VAR == 9) && e.inverse == 2) return;        // (diagnostic knob 14 = 2: main loop only, results invalid)
+        if (e.residual16) {
+            // residual from the limb image its producer wrote (hidden activations of a limb-chained MLP exist only in that form): v = (bias + sum) + residual
+            const int blocks = e.ldr16 >> 4;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (j < nvalid) {
+                    const int col = wave_n0 + j * 32 + li;
+                    const unsigned short* rp = e.residual16 + ((size_t)(wave_m0 + 4 * lh) * blocks + (col >> 4)) * 32 + (col & 15);
+                    unsigned short th[TM][16], tl[TM][16];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned short* q = rp + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * blocks * 32;
+                            th[i][r] = q[0]; tl[i][r] = q[16];
+                        }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[i][j][r] += (float)__builtin_bit_cast(_Float16, th[i][r]) + (float)__builtin_bit_cast(_Float16, tl[i][r]) * (1.0f / 2048.0f);
+                }
+            }
+        }
+
         // The activation and the output format are wave-uniform run-time values: they are dispatched ONCE, outside the element loops
         // (a `switch (act)` per element compiled to ~12 branches per output value -- incl. the ELU path's expm1f -- and cost the
         // 256x128 tile 18 us per tile, 40 % of a 512 -> 512 layer; round 2).  Each body below is straight-line code over the tile.
@@ -1274,7 +1296,7 @@ int guard_resolve() {
 
 template <int BM, int BN, int WM, int WN, int EPI, int VAR = 2>
 static void launch_cfg(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : VAR == 11 ? 2 * (size_t)(BM + BN) * 128 + 1024 : (VAR == 9 || VAR == 10) ? 2 * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 6 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
+    constexpr size_t lds_main = VAR == 8 ? 3 * (size_t)(BM + BN) * 128 : VAR == 11 ? 2 * (size_t)(BM + BN) * 128 + 1024 : (VAR == 9 || VAR == 10) ? (BM == 64 ? 8 : 2) * (size_t)(BM + BN) * 128 : (VAR == 5 || VAR == 6 || VAR == 7) ? 2 * (size_t)(BM + BN) * 80 : VAR >= 3 ? 2 * (size_t)(BM + BN) * 112 : 2 * (size_t)(BM + BN) * LDS_LD * sizeof(float);
     static PerDeviceOnce attr_once;
     constexpr size_t lds_epi = EPI == EPI_SPLINE && VAR != 10 && VAR != 11 ? ((size_t)BM * (BN + 1) + (size_t)BM * 9) * sizeof(float) : 0;   // tile + <= 9 dims of log-dets
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;

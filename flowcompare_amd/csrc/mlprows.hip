@@ -256,7 +256,6 @@ void mlp_rows_kernel(const MlpRowsParams p) {
         // which issue at ~7 cycles instead of 4 with one wave per SIMD, and a slot of six of them outlasts its MFMA.  The arithmetic is
         // fc_gelu's and the split-fp16 GEMM epilogue's, operation for operation.
         float ev[2][4], eu[2][4], eg[2][4];            // [quarter & 1]: a stage of a 16- or 24-k-step layer runs two quarters side by side
-        _Float16 ehh[2][4], ell[2][4];                 // a finished value's limbs
         auto epi_step = [&](const floatx16& pa, const floatx16& pc, auto g_tag, auto m_tag) __attribute__((always_inline)) {
             constexpr int g = decltype(g_tag)::value, m = decltype(m_tag)::value, pr = m / 12, hs = m % 12, Q = g & 1;
             static_assert(ACT == FC_ACT_GELU, "the interleaved epilogue is written for the exact-erf GELU of the shipped configurations");
@@ -277,7 +276,7 @@ void mlp_rows_kernel(const MlpRowsParams p) {
                         const mr_u4& rl = g < 2 ? resA_lo : resB_lo;
                         const unsigned hw = (g & 1) ? (pr == 0 ? rh.z : rh.w) : (pr == 0 ? rh.x : rh.y);
                         const unsigned lw = (g & 1) ? (pr == 0 ? rl.z : rl.w) : (pr == 0 ? rl.x : rl.y);
-                        v += tt ? fmaf(mr_hi(lw), 1.0f / 2048.0f, mr_hi(hw)) : fmaf(mr_lo(lw), 1.0f / 2048.0f, mr_lo(hw));
+                        v += tt ? limb_join<1>(hw, lw) : limb_join<0>(hw, lw);             // (one v_fma_mix_f32, activations.h)
                     }
                     MR_PIN(v);
                     ev[Q][t] = v;
@@ -293,37 +292,33 @@ void mlp_rows_kernel(const MlpRowsParams p) {
                     MR_PIN(gp);
                     eg[Q][t] = gp;
                 } else if constexpr (hs == 5) {
-                    float gp = fmaf(eg[Q][t], eu[Q][t], C[11]);
+                    float gp = fmaf(eg[Q][t], eu[Q][t], C[11] - 1.0f);        // (- 1: erfc(u) / 2 in the log2 domain, activations.h)
                     gp = fmaf(-1.4426950408889634f * eu[Q][t], eu[Q][t], gp);
                     MR_PIN(gp);
                     eg[Q][t] = gp;
                 } else if constexpr (hs == 6) {
-                    float e = __builtin_amdgcn_exp2f(eg[Q][t]);                // erfc(u)
-                    float h = (0.5f * ev[Q][t]) * e;                           // v Phi(-|v|), signed like v
+                    float e = __builtin_amdgcn_exp2f(eg[Q][t]);                // erfc(u) / 2
+                    float h = ev[Q][t] * e;                                    // v Phi(-|v|), signed like v
                     MR_PIN(h);
                     eg[Q][t] = h;
                 } else if constexpr (hs == 7) {
-                    // fc_gelu's `v > 0 ? v - h : h` without the compare / select: max(v, 0) - |h| (the same value bit for bit, up to the sign of a zero)
-                    float r = fmaxf(ev[Q][t], 0.f) - fabsf(eg[Q][t]);
+                    // fc_gelu's max(v, 0) - |h|; the maximum as asm: behind MR_PIN the compiler no longer knows that v is canonical and puts a
+                    // v_max v, v, v in front of fmaxf
+                    float m;
+                    asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(ev[Q][t]));
+                    float r = m - fabsf(eg[Q][t]);
                     MR_PIN(r);
                     ev[Q][t] = r;
                 } else if constexpr (hs == 8) {
-                    const _Float16 hh = (_Float16)ev[Q][t];
-                    float d = ev[Q][t] - (float)hh;
-                    MR_PIN(d);
-                    eg[Q][t] = d; ehh[Q][t] = hh;
-                } else if constexpr (hs == 9) {
-                    _Float16 ll = (_Float16)(eg[Q][t] * 2048.0f);
-                    ell[Q][t] = ll;
                     if (tt == 1) {
-                        // the pair's hi halves and lo' halves as one word each (v_pack_b32_f16)
-                        unsigned wh2 = mr_pack(ehh[Q][2 * pr], ehh[Q][2 * pr + 1]);
-                        unsigned wl2 = mr_pack(ell[Q][2 * pr], ell[Q][2 * pr + 1]);
+                        // the pair's limb words in 5 instructions (activations.h limb_split2)
+                        unsigned wh2, wl2;
+                        limb_split2(ev[Q][2 * pr], ev[Q][2 * pr + 1], wh2, wl2);
                         MR_PIN(wh2); MR_PIN(wl2);
                         outq[g][0][pr] = wh2;
                         outq[g][1][pr] = wl2;
                     }
-                } else if constexpr (hs == 10) {
+                } else if constexpr (hs == 9) {
                     if (tt == 1) {
                         // running maximum of |output| for the range flag (pad rows replicate the last valid row: no masking)
                         float om = fmaxf(omax, fmaxf(fabsf(ev[Q][2 * pr]), fabsf(ev[Q][2 * pr + 1])));
@@ -561,6 +556,16 @@ static void mr_launch(const MlpRowsParams& p, int rows_alloc, double flops, hipS
     ProfScope ps(name, flops, 0.0, s);
     hipLaunchKernelGGL(kern, dim3(rows_alloc / 128), dim3(256), MR_LDS, s, p);
     FC_HIP(hipGetLastError());
+}
+
+bool mlp_rows_fills_the_chip(int rows_alloc) {
+    static PerDeviceOnce cus_once;
+    const int cus = cus_once.run([](int dev) {
+        int n = 0;
+        FC_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        return n;
+    });
+    return rows_alloc / 128 >= (3 * cus) / 4;
 }
 
 bool mlp_rows_eligible(const PackedLinear& in, const std::vector<PackedLinear>& mid, int act) {

@@ -407,19 +407,20 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int b = 0; b < 7; ++b) { nh[b] = nh[b + 1]; nl[b] = nl[b + 1]; }
+        float res[8], xv[8];
+        if constexpr (RESID) limb_join8(rh, rl, res);                   // (one v_fma_mix_f32 per value, activations.h)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float x = t[e] + bs[e];
-            if constexpr (RESID) x += (float)rh[e] + (float)rl[e] * (1.0f / 2048.0f);
+            if constexpr (RESID) x += res[e];
             if constexpr (A == FC_ACT_GELU) x = fc_gelu(x);
             else if constexpr (A == FC_ACT_RELU) x = x > 0.f ? x : 0.f;
             else if constexpr (A == FC_ACT_ELU) x = x > 0.f ? x : expm1f(x);
             else if constexpr (A == FC_ACT_LRELU02) x = x > 0.f ? x : 0.2f * x;
             amax = fmaxf(amax, fabsf(x));
-            const _Float16 h = (_Float16)x;
-            nh[7][e] = h;
-            nl[7][e] = (_Float16)((x - (float)h) * 2048.0f);
+            xv[e] = x;
         }
+        limb_split8(xv, nh[7], nl[7]);                                  // (five instructions per pair of values)
     };
     // one layer, software-pipelined: iteration c issues the MFMAs of chunk c and, behind them in the same basic block, the epilogue of
     // chunk c - 1 (iteration 0 pushes a dummy that the eight real pushes shift out again)
@@ -489,15 +490,16 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         sq += __shfl_xor(sq, 32, 64);
         const float rstd = 1.0f / sqrtf(sq * (1.0f / PM_H) + 1e-5f);
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < 8; ++b) {
+            float xv[8];
+            limb_join8(ah[b], al[b], xv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float x = (((float)ah[b][e] + (float)al[b][e] * (1.0f / 2048.0f)) - mean) * rstd;
-                amax = fmaxf(amax, fabsf(x));
-                const _Float16 h = (_Float16)x;
-                ah[b][e] = h;
-                al[b][e] = (_Float16)((x - (float)h) * 2048.0f);
+                xv[e] = (xv[e] - mean) * rstd;
+                amax = fmaxf(amax, fabsf(xv[e]));
             }
+            limb_split8(xv, ah[b], al[b]);
+        }
     }
 
     PR_STAMP(6)

@@ -109,7 +109,7 @@ M5 = 16384
 
 
 def test_c5_knn_at_16384_points_against_fp64():
-    for C, seed in ((6, 51), (64, 52)):
+    for C, seed in ((6, 51), (64, 52)):                  # (M >= 2048: the matrix-core kernel, csrc/knn.hip)
         g = torch.Generator().manual_seed(seed)
         f = torch.rand(1, M5, C, generator=g) * 2 - 1
         idx = engine.op_knn(f.to(DEV), 40).cpu().long()
