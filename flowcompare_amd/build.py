@@ -2,6 +2,7 @@
 
     python -m flowcompare_amd.build            # incremental
     python -m flowcompare_amd.build --force
+    python -m flowcompare_amd.build --dev      # with the developer kernel variants (-DFC_DEV_VARIANTS; default builds leave them out)
 
 hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
 """
@@ -40,8 +41,23 @@ def _newer(a, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, dev=None):
+    """dev=True adds -DFC_DEV_VARIANTS: the kernel variants that lost an A/B (csrc/common.h FC_DEV) are compiled in and reachable through
+    fc_debug_set; the default library holds the shipped kernels, the bf16-limb range fallback and one fp32-input reference loop.  The choice is
+    remembered in _obj/.dev so that an incremental build does not mix objects; switching forces a full rebuild."""
     os.makedirs(OBJ, exist_ok=True)
+    marker = os.path.join(OBJ, ".dev")
+    was_dev = os.path.exists(marker)
+    if dev is None:
+        dev = bool(os.environ.get("FC_DEV_VARIANTS"))
+    if dev != was_dev:
+        force = True
+        if dev:
+            open(marker, "w").close()
+        else:
+            os.remove(marker)
+    global FLAGS
+    FLAGS = [f for f in FLAGS if f != "-DFC_DEV_VARIANTS"] + (["-DFC_DEV_VARIANTS"] if dev else [])
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "fcflow.h"))
     jobs = []
@@ -75,4 +91,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, dev=True if "--dev" in sys.argv else None))

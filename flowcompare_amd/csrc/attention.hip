@@ -228,16 +228,14 @@ __global__ __launch_bounds__(256) void kv_limbs_kernel(const float* k, int ldk, 
         for (int which = 0; which < 2; ++which) {
             const float4 x = *reinterpret_cast<const float4*>((which ? v + row * ldv : k + row * ldk) + c);
             const float xs[4] = {x.x, x.y, x.z, x.w};
-            f16x4 h, l;
+            uint2 h, l;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                amax = fmaxf(amax, fabsf(xs[e]));
-                h[e] = (_Float16)xs[e];
-                l[e] = (_Float16)((xs[e] - (float)h[e]) * 2048.0f);
-            }
+            for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(xs[e]));
+            limb_split2(xs[0], xs[1], h.x, l.x);
+            limb_split2(xs[2], xs[3], h.y, l.y);
             unsigned short* dst = (which ? v16 : k16) + row * 2 * DH + c;
-            *reinterpret_cast<f16x4*>(dst) = h;
-            *reinterpret_cast<f16x4*>(dst + DH) = l;
+            *reinterpret_cast<uint2*>(dst) = h;
+            *reinterpret_cast<uint2*>(dst + DH) = l;
         }
     }
     if (amax >= 65504.0f) atomicOr(ovf, 1);

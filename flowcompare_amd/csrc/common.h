@@ -168,6 +168,17 @@ struct GemmEpi {
 // the calling thread: the scope hands the kernels a device flag they raise on such a value, and the entry point that opened the
 // scope repeats its whole computation with the bf16-limb loop (unbounded range) when the flag came back set.  Outside a scope
 // launch_gemm always takes the bf16-limb loop.
+// Kernel variants that lost a same-box A/B are compiled only with -DFC_DEV_VARIANTS (`python -m flowcompare_amd.build --dev`):
+// the default library holds, per role, the shipped kernel, the bf16-limb range fallback and ONE fp32-input reference loop.  In a default build
+// fc_debug_set refuses the knob values that would select a developer variant.
+#ifdef FC_DEV_VARIANTS
+#define FC_DEV(...) __VA_ARGS__
+constexpr bool kDevVariants = true;
+#else
+#define FC_DEV(...)
+constexpr bool kDevVariants = false;
+#endif
+
 // One-time setup per (call site, device) -- hipFuncSetAttribute for > 64 KB of dynamic LDS, the CU count behind a persistent grid: a process
 // may drive several devices and pack from a pool of host threads, so a process-wide `static bool done` is not enough.
 struct PerDeviceOnce {
@@ -241,6 +252,7 @@ void launch_layernorm(float* h, int ld, int width, int rows, hipStream_t s);   /
 // limb_ws, outside an Fp16Guard scope or for dh_pad > 64 the fp32-input MFMA kernel runs
 size_t attention_limb_ws_bytes(long kv_rows, int dh_pad);
 // premlp.hip: fused pre-attention MLP -> LayerNorm -> q projection (one launch instead of six) when the shapes allow it
+bool premlp_rows_ok(int rows_alloc, int ldq, const float* qout, const float* keep_ws, size_t keep_floats);   // the row-resident kernel's launch conditions
 bool premlp_fusable(const PackedLinear& in, const std::vector<PackedLinear>& mid, const PackedLinear& out, const PackedLinear& q);
 void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::vector<PackedLinear>& mid, const PackedLinear& out,
                    const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s, float* keep_ws = nullptr,

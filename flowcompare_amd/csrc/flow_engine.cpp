@@ -579,7 +579,8 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
                           hipStream_t s) {
     const Dims& d = f.d;
     const int ldh = std::max(d.H_pad, 32);
-    if (premlp_fusable(pre.in_layer, pre.mid, pre.out_layer, at.q) && in.lda >= pre.in_layer.K_pad) {
+    if (premlp_fusable(pre.in_layer, pre.mid, pre.out_layer, at.q) && in.lda >= pre.in_layer.K_pad &&
+        (kDevVariants || premlp_rows_ok(w.P_pad, d.I_pad, w.q, w.h[0], (size_t)w.P_pad * ldh))) {
         // the whole chain x1 -> MLP -> LayerNorm -> q in one kernel: the 64-row activation tile stays in LDS (premlp.hip)
         launch_premlp(in.ptr, in.lda, pre.in_layer, pre.mid, pre.out_layer, at.q, act, w.q, d.I_pad, w.P_pad, w.P, s, w.h[0], (size_t)w.P_pad * ldh);
     } else {

@@ -440,14 +440,12 @@ void gemm_f32_kernel(const GemmParams p) {
             _Pragma("unroll") for (int i = 0; i < (ALIMB ? 0 : A3); ++i) {                                         \
                 const float x_[4] = {ra3_##S_[i].x, ra3_##S_[i].y, ra3_##S_[i].z, ra3_##S_[i].w};                  \
                 if constexpr (F16) {                                                                               \
-                    f16x4 h_, l_;                                                                                  \
-                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                             \
-                        amax = fmaxf(amax, fabsf(x_[e_]));                                                         \
-                        h_[e_] = (_Float16)x_[e_];                                                                 \
-                        l_[e_] = (_Float16)((x_[e_] - (float)h_[e_]) * 2048.0f);                                   \
-                    }                                                                                              \
-                    *reinterpret_cast<f16x4*>(sa_ + RPP3 * i * ROWB) = h_;                                          \
-                    *reinterpret_cast<f16x4*>(sa_ + RPP3 * i * ROWB + LIMB_B) = l_;                                 \
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(x_[0]), fabsf(x_[1]))), fmaxf(fabsf(x_[2]), fabsf(x_[3])));  \
+                    uint2 h_, l_;                                  /* five VALU per pair of values (activations.h limb_split2) */ \
+                    limb_split2(x_[0], x_[1], h_.x, l_.x);                                                         \
+                    limb_split2(x_[2], x_[3], h_.y, l_.y);                                                         \
+                    *reinterpret_cast<uint2*>(sa_ + RPP3 * i * ROWB) = h_;                                          \
+                    *reinterpret_cast<uint2*>(sa_ + RPP3 * i * ROWB + LIMB_B) = l_;                                 \
                 } else {                                                                                           \
                     bf16x4 h_, m_, l_;                                                                             \
                     _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                             \
@@ -1338,8 +1336,15 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
     FC_HIP(hipGetLastError());
 }
 
+bool gemm_dev_variants() { return kDevVariants; }
+
 void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const GemmEpi& e_in, int epi_kind, hipStream_t s) {
     if (rows_alloc % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "launch_gemm: rows must be padded to ROW_PAD");
+    const int v_bigtile = kDevVariants ? g_gemm_bigtile : 3;
+    const int v_dma_linear = kDevVariants ? g_gemm_dma_linear : 2;
+    const int v_dma = kDevVariants ? v_dma : 4;
+    const int v_variant = kDevVariants ? g_gemm_variant : (g_gemm_variant < 2 ? 2 : g_gemm_variant);
+    (void)v_bigtile; (void)v_dma_linear; (void)v_dma;
     if (L.K_pad % 32 != 0 || L.N_pad % 32 != 0 || L.nseg < 1 || L.nseg > 3) throw Error(FC_ERR_INVALID, "launch_gemm: bad packing");
     GemmParams p{};
     int kt = 0;
@@ -1360,26 +1365,26 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
                    (double)(L.k_true ? L.k_true : L.K_pad);
     p.W = L.W; p.W3 = L.W3; p.W2 = L.W2; p.ovf = t_fp16_flag; p.K_pad = L.K_pad; p.bias = L.bias; p.colvec = L.colvec; p.N_pad = L.N_pad;
     p.e = e;
-    const bool split = (g_gemm_variant == 3 || g_gemm_variant == 5) && L.W3 != nullptr;
-    const bool f16 = g_gemm_variant == 5 && L.W2 != nullptr && t_fp16_flag != nullptr;
+    const bool split = (v_variant == 3 || v_variant == 5) && L.W3 != nullptr;
+    const bool f16 = v_variant == 5 && L.W2 != nullptr && t_fp16_flag != nullptr;
     if (epi_kind == EPI_LINEAR) {
         if ((!e.C && !e.C16) || (e.C && e.ldc < L.N_pad)) throw Error(FC_ERR_INVALID, "launch_gemm: output pitch smaller than N_pad");
-        if (e.C16 && !(f16 && g_gemm_bigtile == 3 && L.N_pad > 64 && L.N_pad % 16 == 0))
+        if (e.C16 && !(f16 && v_bigtile == 3 && L.N_pad > 64 && L.N_pad % 16 == 0))
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: limb-image output exists on the eight-wave split-fp16 tile only");
         if (e.A16) {
             p.e.inverse = g_spline_ablate;
             // A arrives as the limb image of the producing layer (limb-chained MLP): the copy-only main loops
-            if (!(f16 && g_gemm_bigtile == 3 && L.nseg == 1 && L.N_pad > 64 && L.n_alloc >= round_up(L.N_pad, 128)))
+            if (!(f16 && v_bigtile == 3 && L.nseg == 1 && L.N_pad > 64 && L.n_alloc >= round_up(L.N_pad, 128)))
                 throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: a limb-image A operand needs the split-fp16 loop, one segment and N > 64");
-            if (g_gemm_dma_linear == 2 && g_gemm_small_tiles && (rows_alloc / 128) * ((L.N_pad + 127) / 128) <= 256 && L.N_pad % 64 == 0) {
+            if (v_dma_linear == 2 && g_gemm_small_tiles && (rows_alloc / 128) * ((L.N_pad + 127) / 128) <= 256 && L.N_pad % 64 == 0) {
                 // fewer 128x128 tiles than workgroup slots (C1: 2 x 1024 points = 16 row tiles): four times as many 64x64 tiles, each a
                 // quarter of the MFMA work per k step -- the launch is bound by one workgroup's k loop, not by throughput
                 p.nbm = rows_alloc / 64;
                 launch_cfg<64, 64, 2, 2, EPI_LINEAR, 9>(p, s);
             }
-            else if (g_gemm_dma_linear == 2) { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 2, 2, EPI_LINEAR, 9>(p, s); }
-            else if (g_gemm_dma_linear && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 8>(p, s); }
-            else { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 4, 2, EPI_LINEAR, 7>(p, s); }
+            else if (v_dma_linear == 2) { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 2, 2, EPI_LINEAR, 9>(p, s); }
+            FC_DEV(else if (v_dma_linear && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 8>(p, s); }
+                   else { p.nbm = rows_alloc / 128; launch_cfg<128, 128, 4, 2, EPI_LINEAR, 7>(p, s); })
         } else if (L.N_pad <= 64 || (f16 && g_gemm_small_tiles && !e.C16 && (rows_alloc / 128) * ((L.N_pad + 127) / 128) <= 128 && L.n_alloc >= round_up(L.N_pad, 64))) {
             // (64-wide layers; and fp32-A launches with at most 128 tiles of 128x128: twice as many 128x64 tiles)
             p.nbm = rows_alloc / 128;
@@ -1392,17 +1397,18 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             // 128 -> 118 VGPRs -> 4 waves per SIMD instead of 2): +4 ... +19 % over four waves of 64x64 on every layer shape, and
             // better than the 8-wave 256x128 tile on the wide layers.  knob 3: 3 = that (default), 0 = four 64x64 waves,
             // 1 = 256x128 for N >= 1024, 2 = 256x128 everywhere
-            const bool big = g_gemm_bigtile == 2 || (g_gemm_bigtile == 1 && L.N_pad >= 1024);
-            if (f16 && big && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 5>(p, s); }
-            else if (split && g_gemm_bigtile == 2 && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 3>(p, s); }
-            else {
+            FC_DEV(const bool big = v_bigtile == 2 || (v_bigtile == 1 && L.N_pad >= 1024);
+                   if (f16 && big && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 5>(p, s); }
+                   else if (split && v_bigtile == 2 && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_LINEAR, 3>(p, s); }
+                   else)
+            {
                 p.nbm = rows_alloc / 128;
-                if (f16 && g_gemm_bigtile == 3 && g_gemm_prefetch3) launch_cfg<128, 128, 4, 2, EPI_LINEAR, 6>(p, s);
-                else if (f16 && g_gemm_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_LINEAR, 5>(p, s);
-                else if (f16) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 5>(p, s);
+                FC_DEV(if (f16 && v_bigtile == 3 && g_gemm_prefetch3) launch_cfg<128, 128, 4, 2, EPI_LINEAR, 6>(p, s); else)
+                if (f16 && v_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_LINEAR, 5>(p, s);
+                FC_DEV(else if (f16) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 5>(p, s);)
                 else if (split) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 3>(p, s);
-                else if (g_gemm_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
-                else if (g_gemm_variant == 1) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 1>(p, s);
+                FC_DEV(else if (v_variant == 0) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 0>(p, s);
+                       else if (v_variant == 1) launch_cfg<128, 128, 2, 2, EPI_LINEAR, 1>(p, s);)
                 else launch_cfg<128, 128, 2, 2, EPI_LINEAR, 2>(p, s);
             }
         } else {
@@ -1410,7 +1416,7 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             if (split) launch_cfg<128, 320, 4, 1, EPI_LINEAR, 3>(p, s); else launch_cfg<128, 320, 4, 1, EPI_LINEAR>(p, s);
         }
     } else if (epi_kind == EPI_LNQ) {
-        if (!(f16 && g_gemm_bigtile == 3)) throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: the LayerNorm -> q fold runs on the eight-wave split-fp16 tile only");
+        if (!(f16 && v_bigtile == 3)) throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: the LayerNorm -> q fold runs on the eight-wave split-fp16 tile only");
         if (!e.C || !e.ldj_part || e.d2 % 64 != 0 || L.N_pad != e.d2 + 64 || e.ldc < 64 || e.ldj_pitch < (size_t)rows_alloc || !L.bias)
             throw Error(FC_ERR_INVALID, "launch_gemm: bad LayerNorm -> q fold arguments");
         p.nbm = rows_alloc / 128;
@@ -1426,16 +1432,17 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         if ((K != 4 && K != 8 && K != 16) || L.N_pad != spline_ncols(e.d2, K) || !e.xbuf || !e.ldj_part || e.ldj_pitch < (size_t)rows_alloc)
             throw Error(FC_ERR_INVALID, "launch_gemm: bad fused-spline arguments (layout of spline.h, per-tile log-det buffer)");
         p.nbm = rows_alloc / 128;
-        if (f16 && e.A16 && g_gemm_bigtile == 3) {
+        if (f16 && e.A16 && v_bigtile == 3) {
             if (L.nseg != 1) throw Error(FC_ERR_INVALID, "launch_gemm: a limb-image A operand must be the only segment");
-            if (g_gemm_dma == 4 && K == 8 && L.bias && L.n_alloc >= round_up(L.N_pad, 128)) launch_cfg<128, 128, 4, 1, EPI_SPLINE, 11>(p, s);
-            else if (g_gemm_dma == 3 && K == 8 && L.bias && L.n_alloc >= round_up(L.N_pad, 128)) launch_cfg<128, 128, 4, 1, EPI_SPLINE, 10>(p, s);
-            else if (g_gemm_dma >= 2 && L.n_alloc >= round_up(L.N_pad, 128)) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 9>(p, s);
-            else if (g_gemm_dma == 1 && rows_alloc % 256 == 0 && L.n_alloc >= round_up(L.N_pad, 128)) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_SPLINE, 8>(p, s); }
-            else launch_cfg<128, 128, 4, 2, EPI_SPLINE, 7>(p, s);
+            if (L.n_alloc < round_up(L.N_pad, 128)) throw Error(FC_ERR_INVALID, "launch_gemm: fused spline layer not padded to the 128-column tile grid");
+            if (v_dma == 4 && K == 8 && L.bias) launch_cfg<128, 128, 4, 1, EPI_SPLINE, 11>(p, s);
+            FC_DEV(else if (v_dma == 3 && K == 8 && L.bias) launch_cfg<128, 128, 4, 1, EPI_SPLINE, 10>(p, s);)
+            else if (v_dma >= 2) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 9>(p, s);      // (4 and 16 bins: the LDS-tile epilogue on the four-wave DMA tile)
+            FC_DEV(else if (v_dma == 1 && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_SPLINE, 8>(p, s); }
+                   else launch_cfg<128, 128, 4, 2, EPI_SPLINE, 7>(p, s);)
         }
-        else if (f16 && g_gemm_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_SPLINE, 5>(p, s);
-        else if (f16) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 5>(p, s);
+        else if (f16 && v_bigtile == 3) launch_cfg<128, 128, 4, 2, EPI_SPLINE, 5>(p, s);
+        FC_DEV(else if (f16) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 5>(p, s);)
         else launch_cfg<128, 128, 2, 2, EPI_SPLINE, 3>(p, s);
     } else {
         if (!L.bias || L.N_pad % 64 != 0) throw Error(FC_ERR_INVALID, "launch_gemm: pair-packed epilogue needs bias and N_pad % 64 == 0");
@@ -1443,9 +1450,9 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         // forward direction inside a guard scope: 128x128 tile on eight waves with the split-fp16 loop (a wave's 64 columns are one
         // [first 32 | second 32] pair block); log-dets go to the caller's slot buffer.  Otherwise (inverse, bf16-limb fallback
         // pass, fp32 variants): the 128x320 tile whose workgroup owns whole rows.
-        if (e.A16 && !(epi_kind == EPI_AFFINE && f16 && e.ldj_part && !e.inverse && g_gemm_bigtile == 3 && L.nseg == 1 && L.n_alloc >= round_up(L.N_pad, 128)))
+        if (e.A16 && !(epi_kind == EPI_AFFINE && f16 && e.ldj_part && !e.inverse && v_bigtile == 3 && L.nseg == 1 && L.n_alloc >= round_up(L.N_pad, 128)))
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: a limb-image A operand in a pair-packed epilogue exists for the forward affine coupling only");
-        if (f16 && e.ldj_part && !e.inverse && g_gemm_bigtile == 3) {
+        if (f16 && e.ldj_part && !e.inverse && v_bigtile == 3) {
             if (e.ldj_pitch < (size_t)rows_alloc) throw Error(FC_ERR_INVALID, "launch_gemm: log-det slot pitch smaller than the row count");
             if (e.A16 && g_gemm_small_tiles && (rows_alloc / 128) * ((L.N_pad + 127) / 128) <= 256) { p.nbm = rows_alloc / 64; launch_cfg<64, 64, 2, 1, EPI_AFFINE, 9>(p, s); }   // (small launch: 64x64 tiles, see EPI_LINEAR)
             else if (e.A16) launch_cfg<128, 128, 2, 2, EPI_AFFINE, 9>(p, s);       // limb-chained MLP: copy-only LDS-DMA loop (a wave's 64 columns = one pair block)

@@ -544,7 +544,7 @@ void launch_limb_decode(const unsigned short* img, float* out, int ldo, int rows
 
 extern int g_gemm_stamp;
 unsigned long long* gemm_stamp_buffer(size_t n);
-int g_mlp_rows = 1;          // knob 23: 1 = row-resident coupling MLP chain (shipped), 0 = one GEMM launch per layer
+int g_mlp_rows = 1;          // knob 23: 1 = row-resident coupling MLP chain where it fills the chip (shipped), 2 = at any size, 0 = one GEMM launch per layer
 
 template <int KS0, int ACT, bool STAMPS = false>
 static void mr_launch(const MlpRowsParams& p, int rows_alloc, double flops, hipStream_t s) {
@@ -565,7 +565,7 @@ bool mlp_rows_fills_the_chip(int rows_alloc) {
         FC_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
         return n;
     });
-    return rows_alloc / 128 >= (3 * cus) / 4;
+    return g_mlp_rows == 2 || rows_alloc / 128 >= (3 * cus) / 4;      // (knob 23 = 2: the chain at any size -- tests)
 }
 
 bool mlp_rows_eligible(const PackedLinear& in, const std::vector<PackedLinear>& mid, int act) {

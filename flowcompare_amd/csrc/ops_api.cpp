@@ -24,6 +24,9 @@ extern "C" {
 
 /* tuning knobs for profiles/kernel_bench.py (not part of the stable ABI surface in fcflow.h on purpose) */
 int fc_debug_set(int32_t key, int32_t value) {
+    if (!fc::kDevVariants && ((key == 0 && (value == 0 || value == 1)) || (key == 3 && value != 3) || (key == 8 && value == 1) || (key == 13 && value != 4 && value != 2) ||
+                              (key == 15 && value != 2) || (key == 17 && value != 0)))
+        return FC_ERR_UNSUPPORTED;       /* a developer variant: compiled only with -DFC_DEV_VARIANTS (python -m flowcompare_amd.build --dev) */
     if (key == 0) fc::g_gemm_variant = value;
     else if (key == 2) fc::g_gemm_colgroup = value;
     else if (key == 3) fc::g_gemm_bigtile = value;
@@ -48,6 +51,9 @@ int fc_debug_set(int32_t key, int32_t value) {
     else return FC_ERR_INVALID;
     return FC_OK;
 }
+
+/* 1 when the library was built with the developer kernel variants (-DFC_DEV_VARIANTS) */
+int32_t fc_debug_dev_variants(void) { return fc::kDevVariants ? 1 : 0; }
 
 /* host-side view of the spline parameter layer's column layout (csrc/spline.h) for the CPU tests: column of (transformed dim j, parameter
    pp) and the dim-major position inside a tile that the LDS-tile epilogues store a column at; no device call */

@@ -142,6 +142,7 @@ __device__ __forceinline__ void pm_store_tile(char* smc, const float (&v)[2][16]
     }
 }
 
+#ifdef FC_DEV_VARIANTS      // (the LDS-tile form lost its A/B against the row-resident kernel below: developer builds only)
 __global__ __launch_bounds__(PM_NT) __attribute__((amdgpu_waves_per_eu(2))) void premlp_kernel(const PreMlpParams p) {
     extern __shared__ float smem[];
     char* smc = reinterpret_cast<char*>(smem);
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(PM_NT) __attribute__((amdgpu_waves_per_eu(2))) void
     }
     if (amax >= 65504.0f) atomicOr(p.ovf, 1);
 }
+#endif      // FC_DEV_VARIANTS
 
 // =====================================================================================================================================
 // Row-resident variant (knob 8 = 2): the chain's activations never leave the REGISTERS.
@@ -539,6 +541,13 @@ bool premlp_fusable(const PackedLinear& in, const std::vector<PackedLinear>& mid
            q.K_pad == PM_H && q.k_true == PM_H;
 }
 
+// launch conditions of the row-resident kernel (the caller hands it 256 floats of scratch per row: a workspace planned for narrower coupling
+// nets does not have them, and the pre-conditioner then runs as separate launches)
+bool premlp_rows_ok(int rows_alloc, int ldq, const float* qout, const float* keep_ws, size_t keep_floats) {
+    return rows_alloc % PR_ROWS == 0 && ldq % 4 == 0 && ((uintptr_t)qout & 15) == 0 && keep_ws && ((uintptr_t)keep_ws & 15) == 0 &&
+           keep_floats >= (size_t)rows_alloc * PM_H;
+}
+
 extern int g_gemm_stamp;
 unsigned long long* gemm_stamp_buffer(size_t n);      // gemm.hip: the knob-20 stamp buffer (grown on demand), read back by fc_debug_gemm_stamps
 
@@ -546,8 +555,10 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
                    const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s, float* keep_ws, size_t keep_floats) {
     if (rows_alloc % PM_ROWS != 0 || ldx % 4 != 0 || ldx < in.K_pad || ((uintptr_t)x & 15))
         throw Error(FC_ERR_INVALID, "premlp: rows must be padded to 64, input pitch to 4 floats");
+#ifdef FC_DEV_VARIANTS
     static PerDeviceOnce attr_once;
     attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(premlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PM_LDS)); return 0; });
+#endif
     PreMlpParams p{};
     p.x = x; p.ldx = ldx;
     auto L = [](const PackedLinear& l) { return PreMlpLayer{l.W2, l.bias, l.K_pad}; };
@@ -556,8 +567,7 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
     p.stamps = g_gemm_stamp == 3 ? gemm_stamp_buffer((size_t)(rows_alloc / PR_ROWS) * 16) : nullptr;
     const double rv = rows_valid > 0 ? rows_valid : rows_alloc;
     const double flops = 2.0 * rv * ((double)in.k_true * PM_H + 3.0 * PM_H * PM_H + (double)PM_H * (q.n_true ? q.n_true : 64));
-    if (g_premlp_fused == 2 && rows_alloc % PR_ROWS == 0 && ldq % 4 == 0 && ((uintptr_t)qout & 15) == 0 && keep_ws && ((uintptr_t)keep_ws & 15) == 0 &&
-        keep_floats >= (size_t)rows_alloc * PM_H) {
+    if ((g_premlp_fused == 2 || !kDevVariants) && premlp_rows_ok(rows_alloc, ldq, qout, keep_ws, keep_floats)) {
         auto go = [&](auto kern) {
             static PerDeviceOnce attr_once;                             // (one per kernel instantiation: `go` is a generic lambda)
             attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS)); return 0; });
@@ -575,9 +585,13 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
         }
         return;
     }
+#ifdef FC_DEV_VARIANTS
     ProfScope ps("fc::premlp_kernel(fc::PreMlpParams)", flops, 0.0, s);
     hipLaunchKernelGGL(premlp_kernel, dim3(rows_alloc / PM_ROWS), dim3(PM_NT), PM_LDS, s, p);
     FC_HIP(hipGetLastError());
+#else
+    throw Error(FC_ERR_UNSUPPORTED, "launch_premlp: the row-resident kernel's launch conditions do not hold (callers check premlp_rows_ok)");
+#endif
 }
 
 }  // namespace fc

@@ -276,12 +276,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto split_store = [&](char* base, const float4& v) {
         amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-        f16x4 hi, lo;
-        hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-        lo[0] = (_Float16)((v.x - (float)hi[0]) * 2048.0f); lo[1] = (_Float16)((v.y - (float)hi[1]) * 2048.0f);
-        lo[2] = (_Float16)((v.z - (float)hi[2]) * 2048.0f); lo[3] = (_Float16)((v.w - (float)hi[3]) * 2048.0f);
-        *reinterpret_cast<f16x4*>(base) = hi;
-        *reinterpret_cast<f16x4*>(base + 256) = lo;
+        uint2 hi, lo;                                       // five VALU per pair of values (activations.h limb_split2)
+        limb_split2(v.x, v.y, hi.x, lo.x);
+        limb_split2(v.z, v.w, hi.y, lo.y);
+        *reinterpret_cast<uint2*>(base) = hi;
+        *reinterpret_cast<uint2*>(base + 256) = lo;
     };
     // transposed-read address of this lane inside a [4 rows][16 columns] block (attention.hip): lane 4q+c of a 16-lane group supplies
     // row q, columns 4c .. 4c+3; the group's columns are 16 ((lane >> 4) & 1) .. +15 of the 32-column block, its rows start at 4 lh

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "activations.h"
 
 namespace fc {
 
@@ -219,11 +220,8 @@ typedef short v4i16 __attribute__((ext_vector_type(4)));
 constexpr int A16_PITCH = 256 + 16;        // bytes per staged row: [hi 64 halfs | lo' 64 halfs] + pad
 
 __device__ __forceinline__ void split8(const float* v, f16x8& hi, f16x8& lo) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        hi[i] = (_Float16)v[i];
-        lo[i] = (_Float16)((v[i] - (float)hi[i]) * 2048.0f);
-    }
+    const float x[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    limb_split8(x, hi, lo);                                 // five VALU per pair of values (activations.h)
 }
 // 32 x 64 fp32 rows (row stride ld) -> limbs in LDS; rows >= valid come out as zeros.  256 threads, 8 consecutive columns each.
 __device__ __forceinline__ float stage_limbs(const float* __restrict__ src, int ld, int row0, int valid, char* dst, int tid) {

@@ -245,11 +245,14 @@ def test_deferred_range_check_queues_forwards_back_to_back_and_still_repeats_out
 
 
 def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
-    """The shipped fast paths (split-fp16 GEMM on eight-wave tiles, fused spline epilogue, split-fp16 attention) against the
-    variants they replaced or that lost an A/B (fused pre-attention chain kernel), which stay in the library: same log-probs within the
-    fp32 noise of a 4-layer flow at the real layer widths."""
+    """The shipped fast paths (split-fp16 GEMM on eight-wave tiles, fused spline epilogue, split-fp16 attention, row-resident chains)
+    against the paths that stay in the library beside them -- the per-layer launches small batches take, the unfused spline of the inverse
+    direction, the bf16-limb range fallback, the fp32-input reference loop -- and, in a developer build (python -m flowcompare_amd.build
+    --dev), against every variant that lost an A/B: same log-probs within the fp32 noise of a 4-layer flow at the real layer widths, and
+    bit-identical ones where the arithmetic is the same.  A default build refuses the developer knob values: those cases are skipped."""
     from flowcompare_amd import engine
     lib = engine.lib()
+    dev = bool(lib.fc_debug_dev_variants())
     cfg = fa.named_config("c2_dgcnn_attn_spline", n_flow_layers=4, sample_size=300)
     torch.manual_seed(7)
     md = fa.initialize_flow(cfg, device=DEV, mode="test")
@@ -259,42 +262,57 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     eps = [torch.randn(B, N, 294, generator=g).to(DEV)]
     batch = (e0.to(DEV), e1.to(DEV), None)
     defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 2, 9: 1, 10: 1, 13: 4, 15: 2, 16: 1, 17: 0, 19: 0, 21: 0, 22: 1, 23: 1}
-    try:
-        _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
-        for name, knobs in (("one GEMM launch per coupling-MLP layer instead of the row-resident chain", {23: 0}), ("unfused spline", {7: 0}), ("LDS-tile pre-attention chain kernel", {8: 1}), ("separate pre-attention GEMM launches + LayerNorm -> q fold", {8: 0}), ("separate LayerNorm + q projection", {8: 0, 10: 0}), ("no limb chain", {9: 0}), ("limb chain into the spline GEMM only", {16: 0}), ("limb chain into the spline GEMM only, per-layer launches", {23: 0, 16: 0}), ("limb-chained pre-attention MLP", {8: 0, 19: 1}), ("limb-chained hidden layers on the register-staged tile", {23: 0, 15: 0}), ("limb-chained hidden layers on the 256x128 DMA tile", {23: 0, 15: 1}), ("fp32-input attention", {5: 0}),
-                            ("four-wave tile", {3: 0}), ("256x128 tile", {3: 2}), ("bf16-limb GEMM", {0: 3}), ("fp32-input MFMA GEMM", {0: 2})):
+
+    def run_with(knobs):
+        """log-probs under the given knob values, or None when this build refuses one of them (a developer variant)"""
+        try:
             for k, v in knobs.items():
-                lib.fc_debug_set(k, v)
-            _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+                if lib.fc_debug_set(k, v) != 0:
+                    assert not dev, f"knob {k} = {v} refused by a developer build"
+                    return None
+            return fa.inner_loop(batch, md, cfg, eps=eps)[1]
+        finally:
             for k in knobs:
                 lib.fc_debug_set(k, defaults[k])
+
+    try:
+        _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+        n_run = 0
+        for name, knobs in (("unfused spline", {7: 0}), ("LDS-tile pre-attention chain kernel", {8: 1}), ("separate pre-attention GEMM launches + LayerNorm -> q fold", {8: 0}), ("separate LayerNorm + q projection", {8: 0, 10: 0}), ("no limb chain", {9: 0}), ("limb chain into the spline GEMM only", {16: 0}), ("limb-chained pre-attention MLP", {8: 0, 19: 1}), ("limb-chained hidden layers on the register-staged tile", {15: 0}), ("limb-chained hidden layers on the 256x128 DMA tile", {15: 1}), ("fp32-input attention", {5: 0}),
+                            ("four-wave tile", {3: 0}), ("256x128 tile", {3: 2}), ("bf16-limb GEMM", {0: 3}), ("fp32-input MFMA GEMM", {0: 2})):
+            lp = run_with(knobs)
+            if lp is None:
+                print(f"{name}: developer variant, not in this build")
+                continue
+            n_run += 1
             err = (lp - ref).abs().max().item()
             print(f"{name}: max |log-prob - default path| {err:.2e}")
             assert err < 5e-4, name
+        assert n_run >= 9
+        # the row-resident coupling-MLP chain (the engine takes it where a launch fills the chip; this batch is 3 row tiles: forced) issues the
+        # same MFMAs in the same k order as the per-layer launches and adds bias, residual, GELU and limb split alike: bit-identical
+        lp = run_with({23: 2})
+        assert torch.equal(lp, ref), "the row-resident chain differs from the per-layer launches"
+        lp = run_with({23: 2, 16: 0})
+        assert lp is not None and (lp - ref).abs().max().item() < 5e-4
         # every main loop of the fused spline GEMM issues the same MFMAs in the same k order and hands the same parameters to the same
         # spline arithmetic: the register-staged loop (0), the LDS-DMA loops with the LDS parameter tile (1: 256x128, 2: 128x128), the
         # transposed product evaluated from the accumulator registers with one tile per workgroup (3) and the shipped persistent form
         # (4) give bit-identical log-probs
         for v in (0, 1, 2, 3):
-            lib.fc_debug_set(13, v)
-            _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
-            lib.fc_debug_set(13, 4)
+            lp = run_with({13: v})
+            if lp is None:
+                continue
             print(f"knob 13 = {v}: max |diff| {(lp - ref).abs().max().item():.3e}")
             assert torch.equal(lp, ref), f"fused spline GEMM variant (knob 13 = {v}) differs from the shipped persistent loop"
-        lib.fc_debug_set(21, 1)                                   # rotated k order: another fp32 summation order, same sums
-        _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
-        lib.fc_debug_set(21, 0)
+        lp = run_with({21: 1})                                    # rotated k order: another fp32 summation order, same sums
         err = (lp - ref).abs().max().item()
         print(f"persistent fused spline GEMM with rotated k loops: max |log-prob - default path| {err:.2e}")
         assert err < 5e-4
-        lib.fc_debug_set(22, 0)                                   # 128x128 tiles also for launches with few tiles (this test: 5 row tiles -> 64x64 tiles by default)
-        _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
-        lib.fc_debug_set(22, 1)
+        lp = run_with({22: 0})                                    # 128x128 tiles also for launches with few tiles (this test: 5 row tiles -> 64x64 tiles by default)
         assert torch.equal(lp, ref), "64x64 tiles for small launches changed the limb-chained GEMMs' results"
-        lib.fc_debug_set(17, 1)                                   # three register sets of prefetch instead of two: same MFMAs, same order
-        _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
-        lib.fc_debug_set(17, 0)
-        assert torch.equal(lp, ref), "prefetch depth changed the Linear GEMM's results"
+        lp = run_with({17: 1})                                    # three register sets of prefetch instead of two: same MFMAs, same order
+        assert lp is None or torch.equal(lp, ref), "prefetch depth changed the Linear GEMM's results"
     finally:
         for k, v in defaults.items():
             lib.fc_debug_set(k, v)
@@ -322,7 +340,8 @@ def test_persistent_spline_gemm_walks_several_tiles_per_workgroup():
         try:
             _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
             for v in (3, 2):
-                lib.fc_debug_set(13, v)
+                if lib.fc_debug_set(13, v) != 0:                   # (3 = one tile per workgroup: a developer variant, refused by a default build)
+                    continue
                 _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
                 assert torch.equal(lp, ref), f"{B} x {N}: persistent fused spline GEMM differs from knob 13 = {v}"
         finally:
