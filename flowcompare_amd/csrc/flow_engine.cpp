@@ -462,6 +462,8 @@ static void build_flow(fc_flow& f, const WeightTable& wt) {
         h_pad = std::max(h_pad, max_hidden_pad(b.net));
         if (c.flow_type != FC_FLOW_AFFINE) ldp = b.net.out_layer.N_pad;
         if (c.flow_type == FC_FLOW_EXPONENTIAL) {
+            if (d.d2 > 16)       // the permanent cap of include/fcflow.h (enum fc_flow_type): refused at create, not at the first forward
+                throw Error(FC_ERR_UNSUPPORTED, "ExponentialCoupling: latent_dim - latent_dim/2 > 16 is not supported (the layer emits d2^2 numbers per point)");
             const std::string pt = p + ".transform";
             std::vector<float> sc = {wt.get(pt + ".scale", {1}).data[0], wt.get(pt + ".shift", {1}).data[0],
                                      wt.get(pt + ".rescale", {1}).data[0], wt.get(pt + ".reshift", {1}).data[0]};

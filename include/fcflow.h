@@ -51,6 +51,11 @@ typedef struct fc_tensor {
     int64_t shape[4];
 } fc_tensor;
 
+/* FC_FLOW_EXPONENTIAL (models/exponential_coupling.py:44-58) -- PERMANENT CAP: latent_dim - latent_dim / 2 <= 16, inference and training alike
+ * (fc_flow_create returns FC_ERR_UNSUPPORTED beyond it).  The layer's coupling net emits d2 * d2 + d2 numbers per point (a dense matrix per
+ * point): at the reference's latent width of 300 that is 22 650 outputs and 90 KB of matrix per point and layer, which the reference itself
+ * never runs (no shipped configuration selects this flow_type; its own smoke configurations use single-digit latents).  The per-point
+ * matrix exponential therefore lives in one lane's registers (csrc/misc.hip expm_coupling_kernel) and is not tiled. */
 enum fc_flow_type { FC_FLOW_AFFINE = 0, FC_FLOW_SPLINE = 1, FC_FLOW_EXPONENTIAL = 2 };
 enum fc_scale_fn { FC_SCALE_EXP = 0, FC_SCALE_SIGMOID = 1 };
 enum fc_act { FC_ACT_NONE = 0, FC_ACT_GELU = 1, FC_ACT_RELU = 2, FC_ACT_ELU = 3, FC_ACT_LRELU02 = 4 };
