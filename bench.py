@@ -398,10 +398,10 @@ def main():
         done = threading.Event()
 
         def watchdog():                                   # a leg that hangs (a collective that never completes) must not take the forward line with it
-            if not done.wait(600.0):
-                log(f"rank {rank}: training leg exceeded 600 s -- abandoned")
+            if not done.wait(240.0):
+                log(f"rank {rank}: training leg exceeded 240 s -- abandoned")
                 if out is not None:
-                    out["train"] = {"error": "training leg abandoned after 600 s"}
+                    out["train"] = {"error": "training leg abandoned after 240 s"}
                     print(json.dumps(out), flush=True)
                 os._exit(0 if out is not None else 3)
         threading.Thread(target=watchdog, daemon=True).start()
