@@ -904,13 +904,20 @@ void gemm_f32_kernel(const GemmParams p) {
                             const float u = acc[i][2 * pr][r] + bs, t = acc[i][2 * pr + 1][r] + bt;
                             if constexpr (EPI == EPI_AFFINE) {
                                 // models/affine_coupling.py:23-62: s = exp(u) | (2 sigmoid(u) - 1)(1 - 1e-8) + 1 ; y2 = x2 s + t ; x2 = (y2 - t)/s
-                                float sc;
-                                if (e.scale_fn == FC_SCALE_EXP) sc = expf(u);
-                                else sc = (2.0f * (1.0f / (1.0f + expf(-u))) - 1.0f) * (float)(1.0 - 1e-8) + 1.0f;
+                                // (round 3: the hardware transcendentals the spline path uses, ~8 instead of ~40 VALU per pair: with e = exp(-u),
+                                // (2 sigmoid(u) - 1)(1 - 1e-8) + 1 = 2 / (1 + e) in fp32 -- (float)(1 - 1e-8) IS 1.0f -- and log s = ln 2 - ln(1 + e);
+                                // e = inf (u < -88.7) gives s = 0, log s = -inf like the reference's sigmoid)
+                                float sc, lsc;
+                                if (e.scale_fn == FC_SCALE_EXP) { sc = __builtin_amdgcn_exp2f(u * 1.4426950408889634f); lsc = __builtin_amdgcn_logf(sc) * 0.69314718055994530942f; }   // (log of the ROUNDED s, +-inf included, as the reference takes it)
+                                else {
+                                    const float ope = 1.0f + __builtin_amdgcn_exp2f(u * -1.4426950408889634f);
+                                    sc = 2.0f * __builtin_amdgcn_rcpf(ope);
+                                    lsc = (1.0f - __builtin_amdgcn_logf(ope)) * 0.69314718055994530942f;
+                                }
                                 const float g = gsc;
                                 float* xp = xcol + (size_t)row * e.ldx;
                                 if (e.inverse) *xp = (xv[i][r] - t) / (sc * g);
-                                else { *xp = xv[i][r] * (sc * g) + t; lsum[i][r] += logf(sc); }
+                                else { *xp = xv[i][r] * (sc * g) + t; lsum[i][r] += lsc; }
                             } else if constexpr (EPI == EPI_AUGMENT) {
                                 // models/augmenter.py:49-63 + distributions.py:128-153: z2 = mu + eps*sigma, ldj = -log N(z2; mu, sigma)
                                 float sigma = expf(t);
