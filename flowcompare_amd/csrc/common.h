@@ -256,7 +256,9 @@ bool premlp_rows_ok(int rows_alloc, int ldq, const float* qout, const float* kee
 bool premlp_fusable(const PackedLinear& in, const std::vector<PackedLinear>& mid, const PackedLinear& out, const PackedLinear& q);
 void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::vector<PackedLinear>& mid, const PackedLinear& out,
                    const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s, float* keep_ws = nullptr,
-                   size_t keep_floats = 0);
+                   size_t keep_floats = 0, const PackedLinear* lu = nullptr, const float* xprev = nullptr);
+// the previous flow layer's folded ActNorm + permuter `lu` as a pre-layer of the row-resident kernel: z = lu(xprev) is written to x (premlp.hip)
+bool premlp_lu_fusable(const PackedLinear& lu, const PackedLinear& in, int act, int ldx);
 // mlprows.hip: in_layer + hidden layers of a 512-wide coupling MLP in one launch, activations resident in registers
 size_t mlp_rows_image_bytes(int K_pad);
 void launch_mlp_rows_image(const PackedLinear& L, unsigned short* Wf, hipStream_t s);      // fills L's fragment-major image from L.W2

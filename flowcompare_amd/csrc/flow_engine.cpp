@@ -561,6 +561,10 @@ static FlowWs plan_ws(const fc_flow& f, int B, int N, int M, void* ws, size_t by
     return w;
 }
 
+thread_local float* t_flow_trace = nullptr;
+thread_local size_t t_flow_trace_floats = 0;
+void flow_set_trace(float* buf, size_t floats) { t_flow_trace = buf; t_flow_trace_floats = floats; }
+
 int g_premlp_chain = 0;      // knob 19: limb chain through the pre-attention MLP into the LayerNorm -> q GEMM (K = 256: 8 k-tiles per
                              // output tile, the tile-boundary cost of the DMA loop outweighs its main loop: measured 1 % slower end to end)
 static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_segs, const float* rowscal, FlowWs& w, int act, hipStream_t s,
@@ -577,15 +581,26 @@ static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_s
 }
 
 // pre-conditioner: pre-MLP -> LayerNorm -> q -> attention; result in w.a  (models/cif_block.py:14-20 / augmenter.py:15-16)
+// true when the pre-conditioner (pre, at) reading a latent of pitch ldx runs on the row-resident kernel AND can take the previous layer's folded
+// ActNorm + permuter `lu` as its pre-layer (premlp.hip): decided once per layer pair by flow_forward, which then skips that layer's GEMM launch
+static bool attention_takes_lu(const fc_flow& f, const PackedMLP& pre, const AttnPack& at, const PackedLinear& lu, const FlowWs& w, int act) {
+    const Dims& d = f.d;
+    const int ldh = std::max(d.H_pad, 32);
+    return premlp_fusable(pre.in_layer, pre.mid, pre.out_layer, at.q) && d.ldx >= pre.in_layer.K_pad &&
+           premlp_rows_ok(w.P_pad, d.I_pad, w.q, w.h[0], (size_t)w.P_pad * ldh) && premlp_lu_fusable(lu, pre.in_layer, act, d.ldx);
+}
+
 static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack& at, const ASeg& in, FlowWs& w, int act, int B, int N, int M,
-                          hipStream_t s) {
+                          hipStream_t s, const PackedLinear* lu = nullptr, const float* xprev = nullptr) {
     const Dims& d = f.d;
     const int ldh = std::max(d.H_pad, 32);
     if (premlp_fusable(pre.in_layer, pre.mid, pre.out_layer, at.q) && in.lda >= pre.in_layer.K_pad &&
         (kDevVariants || premlp_rows_ok(w.P_pad, d.I_pad, w.q, w.h[0], (size_t)w.P_pad * ldh))) {
-        // the whole chain x1 -> MLP -> LayerNorm -> q in one kernel: the 64-row activation tile stays in LDS (premlp.hip)
-        launch_premlp(in.ptr, in.lda, pre.in_layer, pre.mid, pre.out_layer, at.q, act, w.q, d.I_pad, w.P_pad, w.P, s, w.h[0], (size_t)w.P_pad * ldh);
+        // the whole chain x1 -> MLP -> LayerNorm -> q in one kernel: the 64-row activation tile stays in LDS (premlp.hip); with `lu` the
+        // previous layer's ActNorm + LU runs in front of it and writes this layer's latent (in.ptr) from xprev
+        launch_premlp(in.ptr, in.lda, pre.in_layer, pre.mid, pre.out_layer, at.q, act, w.q, d.I_pad, w.P_pad, w.P, s, w.h[0], (size_t)w.P_pad * ldh, lu, xprev);
     } else {
+        if (lu) throw Error(FC_ERR_INVALID, "run_attention: a pending ActNorm + LU pre-layer needs the row-resident pre-attention kernel");
         // limb chain through the pre-attention MLP into the LayerNorm -> q GEMM (every hidden activation as a limb image, DMA loops)
         const PackedLinear& pre_last = pre.mid.empty() ? pre.in_layer : pre.mid.back();
         const bool chain = g_premlp_chain && at.has_lnq && gemm_lnq_ok() && gemm_limb_chain_all_ok() && w.h16 && !pre.mid.empty() && at.lnq.W2 != nullptr &&
@@ -628,7 +643,7 @@ static void run_attention(const fc_flow& f, const PackedMLP& pre, const AttnPack
 
 // the conditioned coupling of one block (PreConditionApplier, models/transform.py:47-58), forward or inverse, in place on xc
 static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, const float* rowscal, float* logprob, bool inverse, int B, int N,
-                         int M, hipStream_t s) {
+                         int M, hipStream_t s, const PackedLinear* lu = nullptr, const float* xprev = nullptr, int trace_layer = -1) {
     const Dims& d = f.d;
     const fc_flow_config& c = f.cfg;
     const int ldh = std::max(d.H_pad, 32);
@@ -636,10 +651,17 @@ static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, c
     segs[0] = {xc, d.ldx};
     if (b.has_attn) {
         // CIFblock builds its pre_attention_mlp with GELU regardless of the configured nonlinearity (cif_block.py:61)
-        run_attention(f, b.pre, b.attn, segs[0], w, b.has_cif ? (int)FC_ACT_GELU : c.nonlinearity, B, N, M, s);
+        run_attention(f, b.pre, b.attn, segs[0], w, b.has_cif ? (int)FC_ACT_GELU : c.nonlinearity, B, N, M, s, lu, xprev);
         segs[1] = {w.a, d.I_pad};
     } else {
+        if (lu) throw Error(FC_ERR_INVALID, "run_coupling: a pending ActNorm + LU pre-layer needs an attention pre-conditioner");
         segs[1] = {w.ctxp, d.E_pad};
+    }
+    if (trace_layer >= 0 && t_flow_trace) {
+        // diagnostic trace (fc_debug_flow_trace): the x2 half exactly as this coupling will read it (behind a fused ActNorm + LU pre-layer)
+        if ((size_t)(trace_layer + 1) * w.P * d.d2 > t_flow_trace_floats) throw Error(FC_ERR_INVALID, "fc_debug_flow_trace: buffer too small for n_flow_layers x rows x d2");
+        FC_HIP(hipMemcpy2DAsync(t_flow_trace + (size_t)trace_layer * w.P * d.d2, (size_t)d.d2 * 4, xc + d.d1_pad, (size_t)d.ldx * 4, (size_t)d.d2 * 4, (size_t)w.P,
+                                hipMemcpyDeviceToDevice, s));
     }
     // limb chain: the spline parameter GEMM spans 30 column tiles that would each re-split the same fp32 rows into fp16 limbs; the
     // layer before it writes its output once as the limb image instead (GemmEpi::C16) and the parameter GEMM copies it (A16)
@@ -732,9 +754,6 @@ static Prep prepare(fc_flow& f, const float* ctx, const float* extra, int B, int
 // Diagnostic (fc_debug_flow_trace, ops_api.cpp; tests/fullsize_util.py): when the calling thread has set a buffer, flow_forward copies the
 // x2 half of the latent AS THE COUPLING OF LAYER l WILL READ IT into trace[l][row][d2] -- the fp32 values the spline's inside / outside
 // decision |x2| <= 3 is taken on (models/spline_coupling.py:35-48), so a test can hand the fp64 oracle the HIP run's own decisions.
-thread_local float* t_flow_trace = nullptr;
-thread_local size_t t_flow_trace_floats = 0;
-void flow_set_trace(float* buf, size_t floats) { t_flow_trace = buf; t_flow_trace_floats = floats; }
 
 static int expected_noise(const fc_flow& f) { return (f.has_augment ? 1 : 0) + (f.d.nz > 0 ? f.cfg.n_flow_layers : 0); }
 
@@ -775,6 +794,7 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
         launch_pack_rows(x, d.D, d.d1, xc, d.ldx, 0, d.d1, w.P, s);
         launch_pack_rows(x + d.d1, d.D, d.d2, xc, d.ldx, d.d1_pad, d.d2, w.P, s);
     }
+    const PackedLinear* pend = nullptr;
     for (int l = 0; l < c.n_flow_layers; ++l) {
         BlockPack& b = f.blocks[l];
         if (b.has_cif) {
@@ -786,20 +806,25 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
             es.val = w.cbuf; es.ldval = d.nz_pad; es.val_shift = b.cif.z2_shift; es.val_scale = b.cif.z2_scale; es.logprob = logprob;
             run_cif_dist(f, b.cif, w, xc, es, EPI_SLICE, s);
         }
-        if (t_flow_trace) {
-            if ((size_t)(l + 1) * w.P * d.d2 > t_flow_trace_floats) throw Error(FC_ERR_INVALID, "fc_debug_flow_trace: buffer too small for n_flow_layers x rows x d2");
-            FC_HIP(hipMemcpy2DAsync(t_flow_trace + (size_t)l * w.P * d.d2, (size_t)d.d2 * 4, xc + d.d1_pad, (size_t)d.ldx * 4, (size_t)d.d2 * 4, (size_t)w.P,
-                                    hipMemcpyDeviceToDevice, s));
-        }
-        run_coupling(f, b, w, xc, pr.rowscal, logprob, false, B, N, M, s);
+        // `pend`: the previous layer's folded ActNorm + permuter, not launched yet -- it runs as the pre-layer of this layer's row-resident
+        // pre-attention kernel, reading xc and writing xn, which becomes this layer's latent
+        if (pend) std::swap(xc, xn);
+        run_coupling(f, b, w, xc, pr.rowscal, logprob, false, B, N, M, s, pend, pend ? xn : nullptr, l);
+        pend = nullptr;
         if (b.has_lin) {
-            GemmEpi e{};
-            e.C = xn; e.ldc = d.ldx; e.rows_valid = w.P;
-            ASeg ax{xc, d.ldx};
-            launch_gemm(b.lin, &ax, w.P_pad, e, EPI_LINEAR, s);
-            std::swap(xc, xn);
+            const bool next_takes_it = l + 1 < c.n_flow_layers && f.blocks[l + 1].has_attn && !f.blocks[l + 1].has_cif &&
+                                       attention_takes_lu(f, f.blocks[l + 1].pre, f.blocks[l + 1].attn, b.lin, w, c.nonlinearity);
+            if (next_takes_it) pend = &b.lin;
+            else {
+                GemmEpi e{};
+                e.C = xn; e.ldc = d.ldx; e.rows_valid = w.P;
+                ASeg ax{xc, d.ldx};
+                launch_gemm(b.lin, &ax, w.P_pad, e, EPI_LINEAR, s);
+                std::swap(xc, xn);
+            }
         }
     }
+    if (pend) throw Error(FC_ERR_INVALID, "flow_forward: an ActNorm + LU pre-layer was left pending");
     if (ldj_tiles) launch_ldj_reduce(w.ldjp, ldj_tiles, (size_t)w.P_pad, logprob, w.P, s);
     launch_base_density(xc, d.ldx, d.d1, d.d1_pad, d.d2, logprob, (float)f.log_const, z_out, d.D, w.P, s);
 }

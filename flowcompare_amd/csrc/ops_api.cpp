@@ -17,7 +17,7 @@ struct TmpBuf {
 }  // namespace fc
 
 
-namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
+namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }
 
 extern "C" {
@@ -45,6 +45,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 21) fc::g_spline_prefetch = value;
     else if (key == 22) fc::g_gemm_small_tiles = value;
     else if (key == 23) fc::g_mlp_rows = value;          /* 1 = row-resident coupling MLP chain (mlprows.hip, default), 0 = one GEMM launch per layer */
+    else if (key == 26) fc::g_premlp_lu = value;         /* 1 = ActNorm + LU as a pre-layer of the row-resident pre-attention kernel (default), 0 = its own GEMM launch */
     else if (key == 24) fc::g_knn_mfma = value;          /* 1 = k-NN Gram tiles on the matrix cores (default), 0 = lane-per-candidate kernel */
     else if (key == 20) fc::g_gemm_stamp = value;        /* diagnostic: in-kernel phase stamps of the LDS-DMA fused-spline launches */
     else if (key == 14) fc::g_spline_ablate = value;     /* diagnostic: 1 = fused spline epilogue without the spline evaluation, 2 = main loop only (results invalid) */

@@ -40,6 +40,11 @@ struct PreMlpParams {
     unsigned long long* stamps;         // diagnostic knob 20 = 3: 16 x u64 per workgroup (s_memtime at the layer boundaries; wall clock in 14 / 15)
     float* keep_ws;                     // row-resident kernel: rows x 256 floats of scratch (the second hidden layer's residual, parked as limb fragments)
     int* ovf;
+    // row-resident kernel with the PREVIOUS layer's folded ActNorm + permuter matrix as a pre-layer (premlp_rows_kernel<.., .., NLU > 0>):
+    // z = lu(xprev) is written to xnext (the latent this layer works on) and its first in.K_pad columns feed the in_layer from registers
+    PreMlpLayer lu;
+    const float* xprev; int ldxp;
+    float* xnext; int ldxn;
 };
 
 constexpr int PM_ROWS = 64, PM_H = 256, PM_NT = 512;
@@ -264,6 +269,9 @@ constexpr int PR_ROWS = 128, PR_NT = 512, PR_CH = 32;
 constexpr int PR_BUF = PR_CH * PM_H * 4;                    // 32 KB: one chunk of 32 weight rows at K = 256
 constexpr int PR_BIAS_OFF = 2 * PR_BUF;                     // [5][256] floats: in, mid0, mid1, out, q
 constexpr int PR_LDS = PR_BIAS_OFF + 5 * PM_H * 4;
+// with the ActNorm + LU pre-layer (NLU chunks of 32 outputs, K = 32 NLU): a chunk is 32 rows x 32 NLU x 4 B, its bias follows the five others
+constexpr int pr_buf(int nlu) { return nlu * 32 > PM_H ? PR_CH * nlu * 32 * 4 : PR_BUF; }
+constexpr int pr_lds(int nlu) { return 2 * pr_buf(nlu) + 5 * PM_H * 4 + nlu * 32 * 4; }
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // rows of 16 lanes (a0,a1,a2,a3 | b0,b1,b2,b3):  swap32 -> a = (a0,a1,b0,b1), b = (a2,a3,b2,b3) ;  swap16 -> a = (a0,b0,a2,b2), b = (a1,b1,a3,b3)
@@ -290,11 +298,14 @@ __device__ __forceinline__ void pr_dma(const PreMlpLayer& L, int c, char* dst, i
 
 // KSIN: the in_layer's number of 32-wide k steps when known at compile time (its k loop is then one basic block like the 256-wide
 // layers'), 0 = read it from the layer (branches per k step)
-template <int ACT, int KSIN>
+// NLU: chunks (of 32 outputs) of the fused ActNorm + LU pre-layer, 0 = none (the input rows are read from p.x)
+template <int ACT, int KSIN, int NLU = 0>
 __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void premlp_rows_kernel(const PreMlpParams p) {
     extern __shared__ float smem[];
     char* smc = reinterpret_cast<char*>(smem);
-    float* biasbuf = reinterpret_cast<float*>(smc + PR_BIAS_OFF);
+    constexpr int PRB = pr_buf(NLU);                          // bytes of one weight stage
+    static_assert(NLU == 0 || (KSIN > 0 && KSIN <= NLU && KSIN <= 8), "the pre-layer's first KSIN chunks are the in_layer's input");
+    float* biasbuf = reinterpret_cast<float*>(smc + 2 * PRB);
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = blockIdx.x * PR_ROWS + wave * 16 + n;
@@ -314,7 +325,8 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
         for (int l = 0; l < 5; ++l) biasbuf[l * PM_H + tid] = (Ls[l]->bias && (l < 4 || tid < 64)) ? Ls[l]->bias[tid] : 0.f;
     }
-    pr_dma(p.in, 0, smc, wave, lane, 0);
+    if constexpr (NLU > 0) { if (tid < NLU * 32) biasbuf[5 * PM_H + tid] = p.lu.bias ? p.lu.bias[tid] : 0.f; }
+    pr_dma(NLU > 0 ? p.lu : p.in, 0, smc, wave, lane, 0);
     int grp = 1;                                             // which half of the waves issues the next chunk's pieces
 
     f16x8 ah[8], al[8], nh[8], nl[8];
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // this kernel does not have: fragment (s, limb) of lane tid at keep_frag[(s * 2 + limb) * 512 + tid], 1 KiB per wave instruction
     uint4* keep_frag = reinterpret_cast<uint4*>(p.keep_ws) + (size_t)blockIdx.x * 16 * PR_NT + tid;
     // ---- input row -> operand fragments: lane (n, kg) supplies features 32 s + 8 kg + 0..7 of its point
-    {
+    if constexpr (NLU == 0) {
         const int KS = p.in.K_pad >> 5;
         const float* xr = p.x + (size_t)row * p.ldx + 8 * kg;
 #pragma unroll
@@ -344,6 +356,19 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             }
         }
     }
+    // ---- pre-layer input: the previous layer's latent row (all 32 NLU columns) -> operand fragments
+    f16x8 uh[NLU > 0 ? NLU : 1], ul[NLU > 0 ? NLU : 1];
+    if constexpr (NLU > 0) {
+        const float* xr = p.xprev + (size_t)row * p.ldxp + 8 * kg;
+#pragma unroll
+        for (int s_ = 0; s_ < NLU; ++s_) {
+            const float4 x0 = *reinterpret_cast<const float4*>(xr + 32 * s_), x1 = *reinterpret_cast<const float4*>(xr + 32 * s_ + 4);
+            const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(xs[e]));
+            limb_split8(xs, uh[s_], ul[s_]);
+        }
+    }
     __syncthreads();                                         // biasbuf visible
     PR_STAMP(1)
 
@@ -358,12 +383,12 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             for (int i = 0; i < 4; ++i) { am[mb][i] = 0.f; ac[mb][i] = 0.f; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // own pieces of this chunk have landed
         __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
-        if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PR_BUF, wave, lane, grp);
+        if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
         grp ^= 1;
         after_dma();                                                    // (loads that must not sit in front of the wait above: they get this chunk's time to land)
         const int cpr = L.K_pad >> 2, KS = L.K_pad >> 5;
         const int sw = (cpr & 15) == 0 ? n : (n & 7);
-        const char* wrow = smc + buf * PR_BUF + n * cpr * 16;
+        const char* wrow = smc + buf * PRB + n * cpr * 16;
 #pragma unroll
         for (int s_ = 0; s_ < 8; ++s_) {
             if (KSTAT ? s_ < KSTAT : s_ < KS) {
@@ -454,6 +479,80 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     for (int b = 0; b < 8; ++b)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { nh[b][e] = 0; nl[b][e] = 0; }
+    // ---- pre-layer (NLU > 0): z = W_lu xprev + b_lu, the previous flow layer's folded ActNorm + permuter (models/act_norm.py:37-43,
+    //      models/permuters.py:164-169; flow_engine.cpp build_lin) -- one launch per layer fewer, and its output never crosses HBM on the way
+    //      to this kernel.  Same chunk pipeline as `layer`: iteration c multiplies chunk c (32 outputs, K = 32 NLU from the uh / ul fragments)
+    //      and finishes chunk c - 1: bias, fp32 store of the lane's 8 consecutive columns of its row into xnext (every later kernel of the
+    //      layer reads the latent there), and -- for the first KSIN chunks, x1' -- the limb split into the in_layer's input fragments.
+    if constexpr (NLU > 0) {
+        f16x8 fh[KSIN], fl[KSIN];                                       // FIFO of the in_layer's input fragments (chunk c ends up at index c)
+#pragma unroll
+        for (int b = 0; b < KSIN; ++b)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { fh[b][e] = 0; fl[b][e] = 0; }
+        auto lu_mma = [&](int c, floatx4 (&am)[2], floatx4 (&ac)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { am[mb][i] = 0.f; ac[mb][i] = 0.f; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // own pieces of this chunk have landed
+            __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
+            if (c + 1 < NLU) pr_dma(p.lu, c + 1, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            else pr_dma(p.in, 0, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            grp ^= 1;
+            constexpr int cpr = NLU * 8;                                    // 16-byte chunks per weight row
+            const int sw = (cpr & 15) == 0 ? n : (n & 7);
+            const char* wrow = smc + buf * PRB + n * cpr * 16;
+#pragma unroll
+            for (int s_ = 0; s_ < NLU; ++s_) {
+                const int ch = 4 * (2 * s_ + (kg >> 1)) + (kg & 1);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const char* wr = wrow + mb * 16 * cpr * 16;
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(wr + ((ch) ^ sw) * 16);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(wr + ((ch + 2) ^ sw) * 16);
+                    am[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, uh[s_], am[mb], 0, 0, 0);
+                    ac[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, uh[s_], ac[mb], 0, 0, 0);
+                    ac[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ul[s_], ac[mb], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        };
+        auto lu_finish = [&](const float (&t)[8], int c) __attribute__((always_inline)) {       // chunk c >= 0 (wave-uniform)
+            const float* bp = biasbuf + 5 * PM_H + 32 * c + 8 * kg;
+            const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+            const float z[8] = {t[0] + b0.x, t[1] + b0.y, t[2] + b0.z, t[3] + b0.w, t[4] + b1.x, t[5] + b1.y, t[6] + b1.z, t[7] + b1.w};
+            float* zp = p.xnext + (size_t)row * p.ldxn + 32 * c + 8 * kg;
+            *reinterpret_cast<float4*>(zp) = make_float4(z[0], z[1], z[2], z[3]);
+            *reinterpret_cast<float4*>(zp + 4) = make_float4(z[4], z[5], z[6], z[7]);
+            if (c < KSIN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(z[e]));
+#pragma unroll
+                for (int b = 0; b + 1 < KSIN; ++b) { fh[b] = fh[b + 1]; fl[b] = fl[b + 1]; }
+                limb_split8(z, fh[KSIN - 1], fl[KSIN - 1]);
+            }
+        };
+        float tp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tp[e] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < NLU; ++c) {
+            floatx4 am[2], ac[2];
+            lu_mma(c, am, ac);
+            if (c > 0) lu_finish(tp, c - 1);
+            fold(am, ac, tp);
+        }
+        lu_finish(tp, NLU - 1);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b < KSIN) { ah[b] = fh[b]; al[b] = fl[b]; }
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ah[b][e] = 0; al[b][e] = 0; }
+            }
+        }
+    }
     // ---- in_layer, hidden layer 0 (keep = x; x = act(W x)), hidden layer 1 (x = act(keep + W x)), out_layer (no activation)
     layer(p.in, p.mid0, 0, std::integral_constant<int, KSIN>{}, std::false_type{}, ActT{});
     PR_STAMP(2)
@@ -551,8 +650,18 @@ bool premlp_rows_ok(int rows_alloc, int ldq, const float* qout, const float* kee
 extern int g_gemm_stamp;
 unsigned long long* gemm_stamp_buffer(size_t n);      // gemm.hip: the knob-20 stamp buffer (grown on demand), read back by fc_debug_gemm_stamps
 
+int g_premlp_lu = 1;          // knob 26: 1 = the previous layer's folded ActNorm + LU runs as a pre-layer of the row-resident kernel (shipped), 0 = as its own GEMM launch
+
+// true when `lu` (the previous flow layer's folded ActNorm + permuter, latent pitch ldx) can run as the pre-layer of this pre-conditioner's
+// row-resident kernel: square 320 x 320 in the latent's padded layout, the in_layer reading its first 160 columns, GELU (the instantiated case)
+bool premlp_lu_fusable(const PackedLinear& lu, const PackedLinear& in, int act, int ldx) {
+    return g_premlp_lu && act == FC_ACT_GELU && lu.W2 != nullptr && lu.bias != nullptr && lu.nseg == 1 && lu.K_pad == 320 && lu.N_pad == 320 && ldx == 320 &&
+           lu.n_alloc >= 320 && in.K_pad == 160;
+}
+
 void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::vector<PackedLinear>& mid, const PackedLinear& out,
-                   const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s, float* keep_ws, size_t keep_floats) {
+                   const PackedLinear& q, int act, float* qout, int ldq, int rows_alloc, int rows_valid, hipStream_t s, float* keep_ws, size_t keep_floats,
+                   const PackedLinear* lu, const float* xprev) {
     if (rows_alloc % PM_ROWS != 0 || ldx % 4 != 0 || ldx < in.K_pad || ((uintptr_t)x & 15))
         throw Error(FC_ERR_INVALID, "premlp: rows must be padded to 64, input pitch to 4 floats");
 #ifdef FC_DEV_VARIANTS
@@ -566,8 +675,22 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
     p.act = act; p.qout = qout; p.ldq = ldq; p.rows = rows_alloc; p.ovf = gemm_fp16_flag(); p.keep_ws = keep_ws;
     p.stamps = g_gemm_stamp == 3 ? gemm_stamp_buffer((size_t)(rows_alloc / PR_ROWS) * 16) : nullptr;
     const double rv = rows_valid > 0 ? rows_valid : rows_alloc;
-    const double flops = 2.0 * rv * ((double)in.k_true * PM_H + 3.0 * PM_H * PM_H + (double)PM_H * (q.n_true ? q.n_true : 64));
+    double flops = 2.0 * rv * ((double)in.k_true * PM_H + 3.0 * PM_H * PM_H + (double)PM_H * (q.n_true ? q.n_true : 64));
     if ((g_premlp_fused == 2 || !kDevVariants) && premlp_rows_ok(rows_alloc, ldq, qout, keep_ws, keep_floats)) {
+        if (lu) {
+            // the previous layer's ActNorm + LU as a pre-layer: x (this layer's latent buffer) is WRITTEN here, xprev is read
+            if (!premlp_lu_fusable(*lu, in, act, ldx) || !xprev || ((uintptr_t)xprev & 15))
+                throw Error(FC_ERR_INVALID, "launch_premlp: the ActNorm + LU pre-layer does not fit the row-resident kernel (callers check premlp_lu_fusable)");
+            p.lu = L(*lu); p.xprev = xprev; p.ldxp = ldx; p.xnext = const_cast<float*>(x); p.ldxn = ldx;
+            flops += 2.0 * rv * (double)(lu->k_true ? lu->k_true : lu->K_pad) * (double)(lu->n_true ? lu->n_true : lu->N_pad);
+            auto kern = premlp_rows_kernel<FC_ACT_GELU, 5, 10>;
+            static PerDeviceOnce attr_once;
+            attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pr_lds(10))); return 0; });
+            ProfScope ps("fc::premlp_rows_kernel<lu>(fc::PreMlpParams)", flops, 0.0, s);
+            hipLaunchKernelGGL(kern, dim3(rows_alloc / PR_ROWS), dim3(PR_NT), pr_lds(10), s, p);
+            FC_HIP(hipGetLastError());
+            return;
+        }
         auto go = [&](auto kern) {
             static PerDeviceOnce attr_once;                             // (one per kernel instantiation: `go` is a generic lambda)
             attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS)); return 0; });
@@ -585,6 +708,7 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
         }
         return;
     }
+    if (lu) throw Error(FC_ERR_INVALID, "launch_premlp: the ActNorm + LU pre-layer exists in the row-resident kernel only");
 #ifdef FC_DEV_VARIANTS
     ProfScope ps("fc::premlp_kernel(fc::PreMlpParams)", flops, 0.0, s);
     hipLaunchKernelGGL(premlp_kernel, dim3(rows_alloc / PM_ROWS), dim3(PM_NT), PM_LDS, s, p);
