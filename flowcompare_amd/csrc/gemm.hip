@@ -1364,7 +1364,7 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     if (rows_alloc % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "launch_gemm: rows must be padded to ROW_PAD");
     const int v_bigtile = kDevVariants ? g_gemm_bigtile : 3;
     const int v_dma_linear = kDevVariants ? g_gemm_dma_linear : 2;
-    const int v_dma = kDevVariants ? v_dma : 4;
+    const int v_dma = kDevVariants ? g_gemm_dma : (g_gemm_dma == 2 ? 2 : 4);      // (2: the LDS-tile epilogue on the four-wave DMA tile -- in every build: it serves 4 and 16 bins)
     const int v_variant = kDevVariants ? g_gemm_variant : (g_gemm_variant < 2 ? 2 : g_gemm_variant);
     (void)v_bigtile; (void)v_dma_linear; (void)v_dma;
     if (L.K_pad % 32 != 0 || L.N_pad % 32 != 0 || L.nseg < 1 || L.nseg > 3) throw Error(FC_ERR_INVALID, "launch_gemm: bad packing");

@@ -655,7 +655,7 @@ int g_premlp_lu = 1;          // knob 26: 1 = the previous layer's folded ActNor
 // true when `lu` (the previous flow layer's folded ActNorm + permuter, latent pitch ldx) can run as the pre-layer of this pre-conditioner's
 // row-resident kernel: square 320 x 320 in the latent's padded layout, the in_layer reading its first 160 columns, GELU (the instantiated case)
 bool premlp_lu_fusable(const PackedLinear& lu, const PackedLinear& in, int act, int ldx) {
-    return g_premlp_lu && act == FC_ACT_GELU && lu.W2 != nullptr && lu.bias != nullptr && lu.nseg == 1 && lu.K_pad == 320 && lu.N_pad == 320 && ldx == 320 &&
+    return g_premlp_lu && (g_premlp_fused == 2 || !kDevVariants) && act == FC_ACT_GELU && lu.W2 != nullptr && lu.bias != nullptr && lu.nseg == 1 && lu.K_pad == 320 && lu.N_pad == 320 && ldx == 320 &&
            lu.n_alloc >= 320 && in.K_pad == 160;
 }
 
