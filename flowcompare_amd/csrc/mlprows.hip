@@ -388,9 +388,15 @@ void mlp_rows_kernel(const MlpRowsParams p) {
             auto stage = [&](auto q_tag) __attribute__((always_inline)) {
                 constexpr int q = decltype(q_tag)::value;
                 MR_STAMP(0)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MR_NWAIT) : "memory");       // this wave's pieces of stage gcur have landed
-                MR_STAMP(1)
-                __builtin_amdgcn_s_barrier();                                          // ... everybody's; everybody is done with stage gcur - 1
+                // ONE wait + barrier per PAIR of stages (round 3: the wave stood ~150 cycles at the wait and ~160 at the barrier of every
+                // 24-MFMA stage): behind the barrier of an even stage everybody's pieces of that stage AND the next have landed, and everybody
+                // is done with the stage before -- the slot the pieces issued during the two stages go to (stage g + MR_D lands where
+                // stage g - 2 / g - 1 sat).  Layers are an even number of stages long, so a layer starts on an even stage.
+                if ((gcur & 1u) == 0u) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MR_NWAIT - MR_PPW) : "memory");       // this wave's pieces of stages gcur, gcur + 1 have landed
+                    MR_STAMP(1)
+                    __builtin_amdgcn_s_barrier();
+                }
                 MR_STAMP(2)
                 const char* sb = smc + (gcur % MR_R) * MR_STAGE + lane * 16;
                 ++gcur;
