@@ -117,12 +117,15 @@ def check_spline_rows_against_fp64(label, lp_hip, dec_hip, lp64_hip, lp64_nat, d
     forced to THAT run's decisions (the reference arithmetic's own like-for-like gap).  Rows whose decisions differ from the natural
     fp64 ones are reported (they sit whole 0.366-nat boundary jumps from lp64_nat) but need no special rule: against lp64_hip they are
     ordinary rows."""
-    lp_hip, lp64_hip, lp64_nat, lp32, lp64_ref = (t.double() for t in (lp_hip, lp64_hip, lp64_nat, lp32, lp64_ref))
+    lp_hip, lp64_hip, lp32, lp64_ref = (t.double() for t in (lp_hip, lp64_hip, lp32, lp64_ref))
+    lp64_nat = None if lp64_nat is None else lp64_nat.double()
     assert torch.isfinite(lp_hip).all()
     k = math.log2(math.e) / input_dim
     d_hip, d_ref = (lp_hip - lp64_hip).abs(), (lp32 - lp64_ref).abs()
     dnats = abs(float(lp_hip.mean() - lp64_hip.mean()))
     bpd_hip, bpd_ref = dnats * k, abs(float(lp32.mean() - lp64_ref.mean())) * k
+    if dec64 is None:                                         # (no natural fp64 run given: nothing to report about flipped decisions)
+        dec64, lp64_nat = dec_hip, lp64_hip
     flipped = torch.stack([(a != b).any(-1)[0] for a, b in zip(dec_hip, dec64)]).any(0)           # rows with at least one decision unlike fp64's own
     n_events = int(sum(int((a != b).sum()) for a, b in zip(dec_hip, dec64)))
     print(f"{label}: ALL {lp_hip.numel()} rows gated, HIP spline decisions forced on the fp64 oracle; mean nats {float(lp64_hip.mean()):.3f}\n"
