@@ -196,9 +196,11 @@ def main():
                          "gradient all-reduce overlapped with backward, clip_grad_norm_, Adam; embedder in train() mode.  Prints its own JSON line "
                          "(metric 'points/sec (training step ...)'); the default forward metric is BASELINE.json's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=2,
+    ap.add_argument("--train-steps", type=int, default=None,
                     help="timed training steps of the `train` object that the default (forward) line carries: after the forward region, one warm-up + "
-                         "this many timed training steps of the same workload (0 = leave the object out)")
+                         "this many timed training steps of the same workload (0 = leave the object out).  Default: 2 on one GPU; 0 under "
+                         "torch.distributed.run with more than one rank -- the multi-rank RCCL gradient exchange has only ever run with one rank on "
+                         "hardware, and a crash there must not take the forward scaling line with it (`--train` or an explicit --train-steps measure it)")
     ap.add_argument("--sync-range-check", action="store_true",
                     help="diagnostic: the round-2 behaviour -- every forward call reads its fp16 range flag back (one stream synchronisation per call) "
                          "instead of the deferred check (fc_range_check_defer: K forwards queued back to back, flags read once at the end of the timed region)")
@@ -213,6 +215,8 @@ def main():
             raise SystemExit(f"unknown --knob {kv}")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.train_steps is None:
+        args.train_steps = 2 if world == 1 else 0
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
