@@ -48,6 +48,7 @@ constexpr int COL_PAD = 32;    // feature widths are padded to this (GEMM BK / M
 // processed.  bench.py derives its `roofline` object from this over the timed region.
 bool prof_enabled();
 void prof_filter(const char* substr);
+void prof_stride(int n);
 struct ProfScope {
     bool on;
     hipStream_t s;

@@ -893,6 +893,7 @@ const char* fc_last_error(void) { return fc::get_last_error(); }
 int fc_profile_enable(int32_t on) { fc::prof_set(on != 0); return FC_OK; }
 int fc_profile_reset(void) { fc::prof_reset(); return FC_OK; }
 int fc_profile_filter(const char* kernel_substr) { fc::prof_filter(kernel_substr); return FC_OK; }
+int fc_profile_stride(int32_t n) { fc::prof_stride(n); return FC_OK; }
 int fc_profile_report(char* buf, size_t cap) {
     FC_API_BEGIN
     const std::string r = fc::prof_report_json();

@@ -212,6 +212,23 @@ void gemm_f32_kernel(const GemmParams p) {
         }
     }
 
+    // 64 x 64 tiles (one 32 x 32 block per wave): the limb-image residual is requested HERE, in front of the k loop, and added behind it as in
+    // every other tile shape -- such a launch lasts one workgroup's life (~9 us), and 32 two-byte loads issued in the epilogue were ~0.7 us of it
+    constexpr bool RES_EARLY = EPI == EPI_LINEAR && VAR == 9 && TM == 1 && TN == 1;
+    unsigned short res_h[RES_EARLY ? 16 : 1], res_l[RES_EARLY ? 16 : 1];
+    if constexpr (RES_EARLY) {
+        if (e.residual16 && nvalid > 0) {
+            const int blocks = e.ldr16 >> 4;
+            const int col = wave_n0 + li;
+            const unsigned short* rp = e.residual16 + ((size_t)(wave_m0 + 4 * lh) * blocks + (col >> 4)) * 32 + (col & 15);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned short* q = rp + (size_t)((r & 3) + 8 * (r >> 2)) * blocks * 32;
+                res_h[r] = q[0]; res_l[r] = q[16];
+            }
+        }
+    }
+
     if constexpr (VAR == 8 || VAR == 9 || VAR == 10) {
         // ================= split-fp16 main loop on LDS-DMA: BOTH operands arrive as fp16 limb images =================
         // A is the image its producer's epilogue wrote (e.A16, [rows][K/16][hi 16 | lo' 16]), W the host-packed one (p.W2): the main
@@ -652,7 +669,13 @@ void gemm_f32_kernel(const GemmParams p) {
     // C/D layout of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), r = 0..15
     if constexpr (EPI == EPI_LINEAR) {
         if ((VAR == 8 || VAR == 9) && e.inverse == 2) return;        // (diagnostic knob 14 = 2: main loop only, results invalid)
-        if (e.residual16) {
+        if constexpr (RES_EARLY) {
+            if (e.residual16 && nvalid > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[0][0][r] += (float)__builtin_bit_cast(_Float16, res_h[r]) + (float)__builtin_bit_cast(_Float16, res_l[r]) * (1.0f / 2048.0f);
+            }
+        } else if (e.residual16) {
             // residual from the limb image its producer wrote (hidden activations of a limb-chained MLP exist only in that form): v = (bias + sum) + residual
             const int blocks = e.ldr16 >> 4;
 #pragma unroll

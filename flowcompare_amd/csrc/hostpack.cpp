@@ -17,6 +17,7 @@ struct ProfRec { hipEvent_t a, b; int name; double flops, bytes; };
 struct ProfState {
     bool on = false;
     std::string filter;               // non-empty: only launches whose kernel name contains it are bracketed
+    int stride = 1, seen = 0;         // of the launches that pass the filter every stride-th one is bracketed (fc_profile_stride)
     std::vector<std::string> names;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
@@ -37,6 +38,7 @@ ProfState g_prof;
 bool prof_enabled() { return g_prof.on; }
 ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : on(g_prof.on), s(stream) {
     if (on && !g_prof.filter.empty() && !strstr(name, g_prof.filter.c_str())) on = false;
+    if (on && g_prof.stride > 1 && (g_prof.seen++ % g_prof.stride) != 0) on = false;
     if (!on) return;
     ProfRec r{g_prof.ev(), g_prof.ev(), g_prof.name_id(name), flops, bytes};
     (void)hipEventRecord(r.a, s);
@@ -48,6 +50,7 @@ ProfScope::~ProfScope() {
 }
 void prof_set(bool on) { g_prof.on = on; }
 void prof_filter(const char* substr) { g_prof.filter = substr ? substr : ""; }
+void prof_stride(int n) { g_prof.stride = n > 1 ? n : 1; g_prof.seen = 0; }
 void prof_reset() {
     for (auto& r : g_prof.recs) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }
     g_prof.recs.clear();

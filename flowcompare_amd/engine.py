@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FCFLOW_LIB", os.path.join(_HERE, "libfcflow.so"))   # FCFLOW_LIB: A/B another build in profiles/kernel_bench.py
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 FLOW_TYPES = {"AffineCoupling": 0, "RationalQuadraticSplineCoupling": 1, "ExponentialCoupling": 2}
 SCALE_FNS = {"exp": 0, "sigmoid": 1}
@@ -26,7 +26,7 @@ EXPORTS = [
     "fc_dgcnn_create", "fc_dgcnn_destroy", "fc_dgcnn_out_dim", "fc_dgcnn_workspace_bytes", "fc_dgcnn_embed_f32",
     "fc_paconv_create", "fc_paconv_destroy", "fc_paconv_out_dim", "fc_paconv_workspace_bytes", "fc_paconv_embed_f32", "fc_op_fps_f32",
     "fc_range_check_defer", "fc_range_check_resolve", "fc_range_check_pending",
-    "fc_profile_enable", "fc_profile_reset", "fc_profile_filter", "fc_profile_report",
+    "fc_profile_enable", "fc_profile_reset", "fc_profile_filter", "fc_profile_stride", "fc_profile_report",
     "fc_op_linear_f32", "fc_op_mlp_hidden_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
     "fc_stage_fps_f32", "fc_stage_co_unit_sphere_f32", "fc_clamp_infs_f32", "fc_change_map_f32",
     "fc_train_linear_pack_bytes", "fc_train_linear_pack_f32", "fc_train_linear_fwd_f32", "fc_train_linear_dgrad_f32",
@@ -509,6 +509,11 @@ def profile_enable(on=True):
 def profile_filter(kernel_substr=None):
     """Bracket only launches whose kernel name contains `kernel_substr` (None = all)."""
     _check(lib().fc_profile_filter(kernel_substr.encode() if kernel_substr else None))
+
+
+def profile_stride(n=1):
+    """Of the launches that pass the filter bracket every `n`-th one only (1 = all); the report then counts the bracketed launches."""
+    _check(lib().fc_profile_stride(int(n)))
 
 
 def profile_reset():

@@ -19,7 +19,9 @@
  *     the caller's dense fp32 device tensors because they change every optimiser step);
  * 4 = + the PAConv embedder's training primitives (softmax / assign_score / centre difference / gathered-row gradients / 3-NN
  *     interpolation), LeakyReLU slope argument of fc_train_edge_fwd_f32 / fc_train_edge_bwd_prep_f32 (0 = ReLU), optimiser step
- *     (fc_train_sqnorm_f32, fc_train_adam_f32).
+ *     (fc_train_sqnorm_f32, fc_train_adam_f32);
+ * 5 = + the deferred range check (fc_range_check_defer / _resolve / _pending);
+ * 6 = + fc_profile_stride (sampled bracketing of the in-library kernel timing).
  */
 #ifndef FCFLOW_H
 #define FCFLOW_H
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 5
+#define FC_ABI_VERSION 6
 
 enum fc_status {
     FC_OK = 0,
@@ -197,6 +199,10 @@ int fc_profile_reset(void);
 /* Bracket only the launches whose kernel name contains kernel_substr (NULL or "" = all): two event records per launch cost
  * about 4 us of stream time each, 3 % of a C2 forward when every launch is bracketed. */
 int fc_profile_filter(const char* kernel_substr);
+/* Of the launches that pass the filter, bracket every n-th one only (n <= 1: all).  A launch-bound run (C1: ~940 launches of 11-16 us
+ * per 13 ms forward, 575 of them the dominant kernel) is slowed by 30 % when each of those is bracketed; a sample of them gives the
+ * same average duration.  Launches, ms, flops and bytes of fc_profile_report then count the bracketed launches only. */
+int fc_profile_stride(int32_t n);
 int fc_profile_report(char* buf, size_t cap);
 
 /* ---- single operators (same kernels as above; exported for unit-level parity tests) ---------- */
