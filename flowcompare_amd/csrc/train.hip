@@ -241,6 +241,7 @@ typedef short v4i16 __attribute__((ext_vector_type(4)));
 constexpr int W16_ROWS = 32;               // rows per staged slab (two MFMA k-steps)
 constexpr int W16_PITCH = 512 + 32;        // bytes per LDS row: [hi 128 halfs | lo' 128 halfs] + pad
 
+typedef unsigned w16_u4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad16_kernel(const float* __restrict__ du, int ldu, int du_cols, const float* __restrict__ x, int ldx,
                                                       int x_cols, int rows_valid, int chunk_rows, int tiles_k, float* __restrict__ part,
                                                       int part_rows, int part_ld, float* __restrict__ colpart, int colpart_ld, int* __restrict__ ovf) {
@@ -265,17 +266,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float4 ra[4], rb[4];
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
     float amax = 0.f;
+    // Operand loads through buffer descriptors (round 3: the SQ counters showed this loop bound by VALU issue, 11 VALU + 1.5 SALU per MFMA, and
+    // ~5 of them were the bounds branches and 64-bit address arithmetic of eight `ok ? load : 0` per slab).  A slab's descriptor starts at its
+    // first row and ends behind row p_end - 1, so rows past the chunk read as zero through the hardware range check; a lane whose four columns
+    // lie beyond the panel's width carries an offset no descriptor reaches.  Per-lane offsets are loop constants: a load is ONE instruction.
+    unsigned va[4], vb[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        va[h] = a_ok ? (unsigned)(((lr + 8 * h) * ldu + n0 + lc) * 4) : 0x80000000u;
+        vb[h] = b_ok ? (unsigned)(((lr + 8 * h) * ldx + k0 + lc) * 4) : 0x80000000u;
+    }
     auto gload = [&](int p0) {
+        const int left = p_end - p0;                      // > 0 at every call
+        const __amdgpu_buffer_rsrc_t ra_d = __builtin_amdgcn_make_buffer_rsrc((void*)(du + (size_t)p0 * ldu), 0, left * ldu * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb_d = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)p0 * ldx), 0, left * ldx * 4, 0x00020000);
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int p = p0 + lr + 8 * h;
-            const bool ok = p < p_end;
-            ra[h] = (ok && a_ok) ? *reinterpret_cast<const float4*>(du + (size_t)p * ldu + n0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[h] = (ok && b_ok) ? *reinterpret_cast<const float4*>(x + (size_t)p * ldx + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra_d, va[h], 0, 0));
+            rb[h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb_d, vb[h], 0, 0));
         }
     };
     auto split_store = [&](char* base, const float4& v) {
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v.x), "v"(v.y));
+        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v.z), "v"(v.w));
         uint2 hi, lo;                                       // five VALU per pair of values (activations.h limb_split2)
         limb_split2(v.x, v.y, hi.x, lo.x);
         limb_split2(v.z, v.w, hi.y, lo.y);
@@ -285,47 +298,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // transposed-read address of this lane inside a [4 rows][16 columns] block (attention.hip): lane 4q+c of a 16-lane group supplies
     // row q, columns 4c .. 4c+3; the group's columns are 16 ((lane >> 4) & 1) .. +15 of the 32-column block, its rows start at 4 lh
     const int tr_off = (4 * lh + ((lane & 15) >> 2)) * W16_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    auto lstore = [&](int st) {
+    // (the bias-gradient column sums exist in the workgroups of the first k tile only: two copies of the loop instead of a select per value)
+    auto run = [&](auto cols_tag) {
+        constexpr bool COLS = decltype(cols_tag)::value;
+        auto lstore = [&](int st) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            if (do_cols) { csum.x += ra[h].x; csum.y += ra[h].y; csum.z += ra[h].z; csum.w += ra[h].w; }
-            split_store(sA + st * STAGE + (lr + 8 * h) * W16_PITCH + lc * 2, ra[h]);
-            split_store(sB + st * STAGE + (lr + 8 * h) * W16_PITCH + lc * 2, rb[h]);
-        }
-    };
-    // software pipeline: slab t is multiplied out of LDS stage t & 1 while slab t + 1 (already in registers) is converted and stored
-    // into the other stage and slab t + 2 is fetched from HBM; one barrier per slab
-    if (p_begin < p_end) { gload(p_begin); lstore(0); }
-    if (p_begin + W16_ROWS < p_end) gload(p_begin + W16_ROWS);
-    int st = 0;
-    for (int p0 = p_begin; p0 < p_end; p0 += W16_ROWS, st ^= 1) {
-        __syncthreads();                                  // stage st is complete; every wave has finished reading stage st ^ 1
+            for (int h = 0; h < 4; ++h) {
+                if constexpr (COLS) { csum.x += ra[h].x; csum.y += ra[h].y; csum.z += ra[h].z; csum.w += ra[h].w; }
+                split_store(sA + st * STAGE + (lr + 8 * h) * W16_PITCH + lc * 2, ra[h]);
+                split_store(sB + st * STAGE + (lr + 8 * h) * W16_PITCH + lc * 2, rb[h]);
+            }
+        };
+        // software pipeline: slab t is multiplied out of LDS stage t & 1 while slab t + 1 (already in registers) is converted and stored
+        // into the other stage and slab t + 2 is fetched from HBM; one barrier per slab
+        if (p_begin < p_end) { gload(p_begin); lstore(0); }
+        if (p_begin + W16_ROWS < p_end) gload(p_begin + W16_ROWS);
+        int st = 0;
+        for (int p0 = p_begin; p0 < p_end; p0 += W16_ROWS, st ^= 1) {
+            __syncthreads();                                  // stage st is complete; every wave has finished reading stage st ^ 1
 #pragma unroll
-        for (int ks = 0; ks < W16_ROWS / 16; ++ks) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
+            for (int ks = 0; ks < W16_ROWS / 16; ++ks) {
+                f16x8 ah[2], al[2], bh[2], bl[2];
 #define FC_TR(PTR_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(PTR_))
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const char* pa = sA + st * STAGE + (16 * ks) * W16_PITCH + (wn * 64 + i * 32) * 2 + tr_off;
-                const char* pb = sB + st * STAGE + (16 * ks) * W16_PITCH + (wk * 64 + i * 32) * 2 + tr_off;
-                ah[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pa), FC_TR(pa + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
-                al[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pa + 256), FC_TR(pa + 256 + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
-                bh[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pb), FC_TR(pb + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
-                bl[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pb + 256), FC_TR(pb + 256 + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
-            }
+                for (int i = 0; i < 2; ++i) {
+                    const char* pa = sA + st * STAGE + (16 * ks) * W16_PITCH + (wn * 64 + i * 32) * 2 + tr_off;
+                    const char* pb = sB + st * STAGE + (16 * ks) * W16_PITCH + (wk * 64 + i * 32) * 2 + tr_off;
+                    ah[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pa), FC_TR(pa + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
+                    al[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pa + 256), FC_TR(pa + 256 + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
+                    bh[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pb), FC_TR(pb + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
+                    bl[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(pb + 256), FC_TR(pb + 256 + 8 * W16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7));
+                }
 #undef FC_TR
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    om[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], om[i][j], 0, 0, 0);
-                    oc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], oc[i][j], 0, 0, 0);
-                    oc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], oc[i][j], 0, 0, 0);
-                }
-            if (ks == 0 && p0 + W16_ROWS < p_end) lstore(st ^ 1);        // the next slab's limbs, under this slab's MFMAs
+                    for (int j = 0; j < 2; ++j) {
+                        om[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], om[i][j], 0, 0, 0);
+                        oc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], oc[i][j], 0, 0, 0);
+                        oc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], oc[i][j], 0, 0, 0);
+                    }
+                if (ks == 0 && p0 + W16_ROWS < p_end) lstore(st ^ 1);        // the next slab's limbs, under this slab's MFMAs
+            }
+            if (p0 + 2 * W16_ROWS < p_end) gload(p0 + 2 * W16_ROWS);
         }
-        if (p0 + 2 * W16_ROWS < p_end) gload(p0 + 2 * W16_ROWS);
-    }
+    };
+    if (do_cols) run(std::true_type{}); else run(std::false_type{});
     if (amax >= 65504.0f || amax != amax) atomicOr(ovf, 1);
     if (do_cols) {
         // the 8 thread rows (tid >> 5) of the staging grid each summed their own rows of the chunk: add them in a fixed order
