@@ -224,21 +224,32 @@ __device__ __forceinline__ void split8(const float* v, f16x8& hi, f16x8& lo) {
     limb_split8(x, hi, lo);                                 // five VALU per pair of values (activations.h)
 }
 // 32 x 64 fp32 rows (row stride ld) -> limbs in LDS; rows >= valid come out as zeros.  256 threads, 8 consecutive columns each.
-__device__ __forceinline__ float stage_limbs(const float* __restrict__ src, int ld, int row0, int valid, char* dst, int tid) {
+// Split in two halves so that a tile's rows can be REQUESTED one tile ahead and converted / stored behind the current tile's products
+// (round 3: both backward kernels staged a tile between two barriers with nothing else in flight -- every tile paid a full memory latency
+// for 36 MFMAs per wave).  The load goes through a buffer descriptor that ends behind row valid - 1: the range check zeroes the rows past
+// the end, no branch, and the per-lane offset is a loop constant.
+struct StageRegs { float4 a, b; };
+__device__ __forceinline__ StageRegs stage_load(const float* __restrict__ src, int ld, int row0, int valid, int tid) {
     const int r = tid >> 3, c = (tid & 7) * 8;
-    float v[8];
-    const bool ok = row0 + r < valid;
-    const float4 a = ok ? *reinterpret_cast<const float4*>(src + (size_t)(row0 + r) * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 b = ok ? *reinterpret_cast<const float4*>(src + (size_t)(row0 + r) * ld + c + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    const size_t bytes = (size_t)(valid - row0) * ld * 4;                       // row0 < valid at every call
+    const __amdgpu_buffer_rsrc_t d = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)row0 * ld), 0, bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes, 0x00020000);
+    const unsigned off = (unsigned)((r * ld + c) * 4);
+    StageRegs g;
+    g.a = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d, off, 0, 0));
+    g.b = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d, off + 16, 0, 0));
+    return g;
+}
+__device__ __forceinline__ void stage_store(const StageRegs& g, char* dst, int tid, float& amax) {
+    const int r = tid >> 3, c = (tid & 7) * 8;
+    const float v[8] = {g.a.x, g.a.y, g.a.z, g.a.w, g.b.x, g.b.y, g.b.z, g.b.w};
     f16x8 hi, lo;
     split8(v, hi, lo);
     *reinterpret_cast<f16x8*>(dst + r * A16_PITCH + c * 2) = hi;
     *reinterpret_cast<f16x8*>(dst + r * A16_PITCH + 128 + c * 2) = lo;
-    float m = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(v[i]));
-    return m;
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v[0]), "v"(v[1]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v[2]), "v"(v[3]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v[4]), "v"(v[5]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v[6]), "v"(v[7]));
 }
 #define FC_TR16(PTR_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(PTR_))
 #define FC_TR16x2(PTR_) __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR16(PTR_), FC_TR16((PTR_) + 8 * A16_PITCH), 0, 1, 2, 3, 4, 5, 6, 7))
@@ -247,10 +258,12 @@ __device__ __forceinline__ float stage_limbs(const float* __restrict__ src, int 
     CROSS_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH_, BL_, CROSS_, 0, 0, 0);      \
     CROSS_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL_, BH_, CROSS_, 0, 0, 0);
 
-__global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int* __restrict__ ovf) {
+// (two waves per SIMD: 247 registers, no scratch -- left to itself hipcc takes 276 and one wave per SIMD: 569 -> 388 us per C2 launch)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd16_dq_kernel(AttnBwdParams p, int* __restrict__ ovf) {
     constexpr int DH = 64;
-    __shared__ __attribute__((aligned(16))) char sK[32 * A16_PITCH];
-    __shared__ __attribute__((aligned(16))) char sV[32 * A16_PITCH];
+    constexpr int ST = 32 * A16_PITCH;                                // one stage; two per operand
+    __shared__ __attribute__((aligned(16))) char sK[2 * ST];
+    __shared__ __attribute__((aligned(16))) char sV[2 * ST];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const int qrow = blockIdx.x * 128 + wave * 32 + li;
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int
     float m = -INFINITY, l = 0.f;
     for (int t = 0; t < (p.have_lse ? 0 : ntiles); ++t) {
         __syncthreads();
-        amax = fmaxf(amax, stage_limbs(kb, p.ldk, t * 32, p.M, sK, tid));
+        stage_store(stage_load(kb, p.ldk, t * 32, p.M, tid), sK, tid, amax);
         __syncthreads();
         f32x16 sm, sc;
 #pragma unroll
@@ -319,21 +332,34 @@ __global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { qm[i][r] = 0.f; qc[i][r] = 0.f; }
+    // software pipeline over the key tiles: tile t is multiplied out of LDS stage t & 1 while tile t + 1 (in registers since the previous
+    // iteration) is converted and stored into the other stage behind the products, and tile t + 2 is requested; ONE barrier per tile
+    StageRegs rk, rv;
+    __syncthreads();                                                   // (pass A may still be reading stage 0)
+    if (ntiles > 0) {
+        stage_store(stage_load(kb, p.ldk, 0, p.M, tid), sK, tid, amax);
+        stage_store(stage_load(vb, p.ldv, 0, p.M, tid), sV, tid, amax);
+    }
+    if (ntiles > 1) { rk = stage_load(kb, p.ldk, 32, p.M, tid); rv = stage_load(vb, p.ldv, 32, p.M, tid); }
     for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();
-        amax = fmaxf(amax, stage_limbs(kb, p.ldk, t * 32, p.M, sK, tid));
-        amax = fmaxf(amax, stage_limbs(vb, p.ldv, t * 32, p.M, sV, tid));
-        __syncthreads();
+        __syncthreads();                                               // stage t & 1 is complete; every wave is done reading the other one
+        const char* const cK = sK + (t & 1) * ST;
+        const char* const cV = sV + (t & 1) * ST;
         f32x16 sm, sc, pm, pc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; pm[r] = 0.f; pc[r] = 0.f; }
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
-            const f16x8 kh = *reinterpret_cast<const f16x8*>(sK + a_off + 32 * ds), kl = *reinterpret_cast<const f16x8*>(sK + a_off + 32 * ds + 128);
-            const f16x8 vh = *reinterpret_cast<const f16x8*>(sV + a_off + 32 * ds), vl = *reinterpret_cast<const f16x8*>(sV + a_off + 32 * ds + 128);
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(cK + a_off + 32 * ds), kl = *reinterpret_cast<const f16x8*>(cK + a_off + 32 * ds + 128);
+            const f16x8 vh = *reinterpret_cast<const f16x8*>(cV + a_off + 32 * ds), vl = *reinterpret_cast<const f16x8*>(cV + a_off + 32 * ds + 128);
             FC_MMA3(sm, sc, kh, kl, Qh[ds], Ql[ds])
             FC_MMA3(pm, pc, vh, vl, Gh[ds], Gl[ds])
         }
+        if (t + 1 < ntiles) {                                          // the next tile's limbs, under this tile's first products
+            stage_store(rk, sK + ((t + 1) & 1) * ST, tid, amax);
+            stage_store(rv, sV + ((t + 1) & 1) * ST, tid, amax);
+        }
+        if (t + 2 < ntiles) { rk = stage_load(kb, p.ldk, (t + 2) * 32, p.M, tid); rv = stage_load(vb, p.ldv, (t + 2) * 32, p.M, tid); }
         float dsv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -347,7 +373,7 @@ __global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int
             split8(dsv + 8 * j, sh, sl);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const char* pk = sK + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
+                const char* pk = cK + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
                 const f16x8 kh = FC_TR16x2(pk), kl = FC_TR16x2(pk + 128);
                 FC_MMA3(qm[i], qc[i], kh, kl, sh, sl)
             }
@@ -362,10 +388,11 @@ __global__ __launch_bounds__(256) void attn_bwd16_dq_kernel(AttnBwdParams p, int
 }
 
 __global__ __launch_bounds__(256) void attn_bwd16_dkv_kernel(AttnBwdParams p, int* __restrict__ ovf) {
-    __shared__ __attribute__((aligned(16))) char sQ[32 * A16_PITCH];
-    __shared__ __attribute__((aligned(16))) char sG[32 * A16_PITCH];
-    __shared__ float sLse[32];
-    __shared__ float sD[32];
+    constexpr int ST = 32 * A16_PITCH;                                // one stage; two per operand (pipeline as in the dq kernel)
+    __shared__ __attribute__((aligned(16))) char sQ[2 * ST];
+    __shared__ __attribute__((aligned(16))) char sG[2 * ST];
+    __shared__ float sLse[2][32];
+    __shared__ float sD[2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const int krow = blockIdx.x * 128 + wave * 32 + li;
@@ -396,33 +423,52 @@ __global__ __launch_bounds__(256) void attn_bwd16_dkv_kernel(AttnBwdParams p, in
     const size_t q0 = (size_t)b * p.N;
     const int a_off = li * A16_PITCH + 16 * h;
     const int tr_off = (4 * h + ((lane & 15) >> 2)) * A16_PITCH + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();
-        amax = fmaxf(amax, stage_limbs(p.q + q0 * p.ldq, p.ldq, t * 32, p.N, sQ, tid));
-        amax = fmaxf(amax, stage_limbs(p.dout + q0 * p.lddo, p.lddo, t * 32, p.N, sG, tid));
+    const float* const qsrc = p.q + q0 * p.ldq;
+    const float* const gsrc = p.dout + q0 * p.lddo;
+    StageRegs rq, rg;
+    float r_lse = INFINITY, r_d = 0.f;
+    auto vec_load = [&](int t) {                                       // per-query log-sum-exp (log2 domain) and D of tile t, lanes 0..31 of wave 0
         if (tid < 32) {
             const int qi = t * 32 + tid;
-            sLse[tid] = qi < p.N ? p.lse[q0 + qi] * 1.4426950408889634f : INFINITY;        // log2 domain; exp2(s - inf) = 0: queries past the end contribute nothing
-            sD[tid] = qi < p.N ? p.dvec[q0 + qi] : 0.f;
+            r_lse = qi < p.N ? p.lse[q0 + qi] * 1.4426950408889634f : INFINITY;          // exp2(s - inf) = 0: queries past the end contribute nothing
+            r_d = qi < p.N ? p.dvec[q0 + qi] : 0.f;
         }
-        __syncthreads();
+    };
+    auto vec_store = [&](int st) { if (tid < 32) { sLse[st][tid] = r_lse; sD[st][tid] = r_d; } };
+    if (ntiles > 0) {
+        stage_store(stage_load(qsrc, p.ldq, 0, p.N, tid), sQ, tid, amax);
+        stage_store(stage_load(gsrc, p.lddo, 0, p.N, tid), sG, tid, amax);
+        vec_load(0); vec_store(0);
+    }
+    if (ntiles > 1) { rq = stage_load(qsrc, p.ldq, 32, p.N, tid); rg = stage_load(gsrc, p.lddo, 32, p.N, tid); vec_load(1); }
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();                                               // stage t & 1 is complete; every wave is done reading the other one
+        const int cur = t & 1;
+        const char* const cQ = sQ + cur * ST;
+        const char* const cG = sG + cur * ST;
         f32x16 sm, sc, pm, pc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; pm[r] = 0.f; pc[r] = 0.f; }
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
-            const f16x8 qh = *reinterpret_cast<const f16x8*>(sQ + a_off + 32 * ds), ql = *reinterpret_cast<const f16x8*>(sQ + a_off + 32 * ds + 128);
-            const f16x8 gh = *reinterpret_cast<const f16x8*>(sG + a_off + 32 * ds), gl = *reinterpret_cast<const f16x8*>(sG + a_off + 32 * ds + 128);
+            const f16x8 qh = *reinterpret_cast<const f16x8*>(cQ + a_off + 32 * ds), ql = *reinterpret_cast<const f16x8*>(cQ + a_off + 32 * ds + 128);
+            const f16x8 gh = *reinterpret_cast<const f16x8*>(cG + a_off + 32 * ds), gl = *reinterpret_cast<const f16x8*>(cG + a_off + 32 * ds + 128);
             FC_MMA3(sm, sc, qh, ql, Kh[ds], Kl[ds])                      // S[query][key]
             FC_MMA3(pm, pc, gh, gl, Vh[ds], Vl[ds])                      // dP[query][key]
         }
+        if (t + 1 < ntiles) {                                          // the next tile's limbs, under this tile's first products
+            stage_store(rq, sQ + (cur ^ 1) * ST, tid, amax);
+            stage_store(rg, sG + (cur ^ 1) * ST, tid, amax);
+            vec_store(cur ^ 1);
+        }
+        if (t + 2 < ntiles) { rq = stage_load(qsrc, p.ldq, (t + 2) * 32, p.N, tid); rg = stage_load(gsrc, p.lddo, (t + 2) * 32, p.N, tid); vec_load(t + 2); }
         float pv[16], dsv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = acc_row(r, h);
-            const float pr = kok ? __builtin_amdgcn_exp2f((sm[r] + sc[r] * (1.0f / 2048.0f)) * sl2 - sLse[qi]) : 0.f;
+            const float pr = kok ? __builtin_amdgcn_exp2f((sm[r] + sc[r] * (1.0f / 2048.0f)) * sl2 - sLse[cur][qi]) : 0.f;
             pv[r] = pr;
-            dsv[r] = pr * ((pm[r] + pc[r] * (1.0f / 2048.0f)) - sD[qi]) * p.scale;
+            dsv[r] = pr * ((pm[r] + pc[r] * (1.0f / 2048.0f)) - sD[cur][qi]) * p.scale;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -431,8 +477,8 @@ __global__ __launch_bounds__(256) void attn_bwd16_dkv_kernel(AttnBwdParams p, in
             split8(dsv + 8 * j, sh, sl);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const char* pg = sG + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
-                const char* pq = sQ + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
+                const char* pg = cG + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
+                const char* pq = cQ + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
                 const f16x8 gh = FC_TR16x2(pg), gl = FC_TR16x2(pg + 128);
                 const f16x8 qh = FC_TR16x2(pq), ql = FC_TR16x2(pq + 128);
                 FC_MMA3(vm[i], vc[i], gh, gl, ph, pl)                    // dV^T[d][key] += dO^T P
