@@ -239,7 +239,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef short v4i16 __attribute__((ext_vector_type(4)));
 
 constexpr int W16_ROWS = 32;               // rows per staged slab (two MFMA k-steps)
-constexpr int W16_PITCH = 512 + 32;        // bytes per LDS row: [hi 128 halfs | lo' 128 halfs] + pad
+constexpr int W16_PITCH = 512 + 64;        // bytes per LDS row: [hi 128 halfs | lo' 128 halfs] + pad.  144 words = 16 banks (of the 64 a ds_read_b64_tr_b16 sees) from
+                                           // row to row: the 32 lanes of one read cycle -- 4 rows x 2 column halves x 4 lanes of 8 bytes -- then cover all 64 banks once
+                                           // (with 512 + 32 a row advanced 8 banks, the distance of the column halves: 2-way conflicts, SQ_LDS_BANK_CONFLICT 33 % of the LDS cycles)
 
 typedef unsigned w16_u4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad16_kernel(const float* __restrict__ du, int ldu, int du_cols, const float* __restrict__ x, int ldx,
