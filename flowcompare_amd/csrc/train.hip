@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         oc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], oc[i][j], 0, 0, 0);
                     }
                 if (ks == 0 && p0 + W16_ROWS < p_end) lstore(st ^ 1);        // the next slab's limbs, under this slab's MFMAs
+                if (ks == 0 && p0 + 2 * W16_ROWS < p_end) gload(p0 + 2 * W16_ROWS);      // ... and the slab after it requested at once: a whole slab to land
             }
-            if (p0 + 2 * W16_ROWS < p_end) gload(p0 + 2 * W16_ROWS);
         }
     };
     if (do_cols) run(std::true_type{}); else run(std::false_type{});
