@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < 16; ++r) p.dq[grow * p.lddq + i * 32 + acc_row(r, h)] = qm[i][r] + qc[i][r] * (1.0f / 2048.0f);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd16_dkv_kernel(AttnBwdParams p, int* __restrict__ ovf) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd16_dkv_kernel(AttnBwdParams p, int* __restrict__ ovf) {
     constexpr int ST = 32 * A16_PITCH;                                // one stage; two per operand (pipeline as in the dq kernel)
     __shared__ __attribute__((aligned(16))) char sQ[2 * ST];
     __shared__ __attribute__((aligned(16))) char sG[2 * ST];
@@ -446,45 +446,68 @@ __global__ __launch_bounds__(256) void attn_bwd16_dkv_kernel(AttnBwdParams p, in
         const int cur = t & 1;
         const char* const cQ = sQ + cur * ST;
         const char* const cG = sG + cur * ST;
-        f32x16 sm, sc, pm, pc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; pm[r] = 0.f; pc[r] = 0.f; }
-#pragma unroll
-        for (int ds = 0; ds < 4; ++ds) {
-            const f16x8 qh = *reinterpret_cast<const f16x8*>(cQ + a_off + 32 * ds), ql = *reinterpret_cast<const f16x8*>(cQ + a_off + 32 * ds + 128);
-            const f16x8 gh = *reinterpret_cast<const f16x8*>(cG + a_off + 32 * ds), gl = *reinterpret_cast<const f16x8*>(cG + a_off + 32 * ds + 128);
-            FC_MMA3(sm, sc, qh, ql, Kh[ds], Kl[ds])                      // S[query][key]
-            FC_MMA3(pm, pc, gh, gl, Vh[ds], Vl[ds])                      // dP[query][key]
-        }
-        if (t + 1 < ntiles) {                                          // the next tile's limbs, under this tile's first products
+        // The next tile's limbs first (the co-resident wave's products cover the conversion), then S, then dP: one pair of score accumulators
+        // live at a time and the staging registers empty from here to the next request -- 256 registers hold the rest (two waves per SIMD)
+        if (t + 1 < ntiles) {
             stage_store(rq, sQ + (cur ^ 1) * ST, tid, amax);
             stage_store(rg, sG + (cur ^ 1) * ST, tid, amax);
             vec_store(cur ^ 1);
         }
-        if (t + 2 < ntiles) { rq = stage_load(qsrc, p.ldq, (t + 2) * 32, p.N, tid); rg = stage_load(gsrc, p.lddo, (t + 2) * 32, p.N, tid); vec_load(t + 2); }
+        __builtin_amdgcn_sched_barrier(0);
         float pv[16], dsv[16];
+        {
+            f32x16 sm, sc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qi = acc_row(r, h);
-            const float pr = kok ? __builtin_amdgcn_exp2f((sm[r] + sc[r] * (1.0f / 2048.0f)) * sl2 - sLse[cur][qi]) : 0.f;
-            pv[r] = pr;
-            dsv[r] = pr * ((pm[r] + pc[r] * (1.0f / 2048.0f)) - sD[cur][qi]) * p.scale;
+            for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const f16x8 qh = *reinterpret_cast<const f16x8*>(cQ + a_off + 32 * ds), ql = *reinterpret_cast<const f16x8*>(cQ + a_off + 32 * ds + 128);
+                FC_MMA3(sm, sc, qh, ql, Kh[ds], Kl[ds])                  // S[query][key]
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                pv[r] = kok ? __builtin_amdgcn_exp2f((sm[r] + sc[r] * (1.0f / 2048.0f)) * sl2 - sLse[cur][acc_row(r, h)]) : 0.f;
         }
+        {
+            f32x16 pm, pc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { pm[r] = 0.f; pc[r] = 0.f; }
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const f16x8 gh = *reinterpret_cast<const f16x8*>(cG + a_off + 32 * ds), gl = *reinterpret_cast<const f16x8*>(cG + a_off + 32 * ds + 128);
+                FC_MMA3(pm, pc, gh, gl, Vh[ds], Vl[ds])                  // dP[query][key]
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                dsv[r] = pv[r] * ((pm[r] + pc[r] * (1.0f / 2048.0f)) - sD[cur][acc_row(r, h)]) * p.scale;
+        }
+        // dV from P, then dK from dS (each accumulator still receives j = 0 before j = 1): fewer operands live at once than with both interleaved
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f16x8 ph, pl, sh, sl;
+            f16x8 ph, pl;
             split8(pv + 8 * j, ph, pl);
-            split8(dsv + 8 * j, sh, sl);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const char* pg = cG + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
-                const char* pq = cQ + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
                 const f16x8 gh = FC_TR16x2(pg), gl = FC_TR16x2(pg + 128);
-                const f16x8 qh = FC_TR16x2(pq), ql = FC_TR16x2(pq + 128);
                 FC_MMA3(vm[i], vc[i], gh, gl, ph, pl)                    // dV^T[d][key] += dO^T P
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f16x8 sh, sl;
+            split8(dsv + 8 * j, sh, sl);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const char* pq = cQ + (16 * j) * A16_PITCH + (32 * i) * 2 + tr_off;
+                const f16x8 qh = FC_TR16x2(pq), ql = FC_TR16x2(pq + 128);
                 FC_MMA3(km[i], kc[i], qh, ql, sh, sl)                    // dK^T[d][key] += Q^T dS
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < ntiles) { rq = stage_load(qsrc, p.ldq, (t + 2) * 32, p.N, tid); rg = stage_load(gsrc, p.lddo, (t + 2) * 32, p.N, tid); vec_load(t + 2); }
     }
     if (amax >= 65504.0f || amax != amax) atomicOr(ovf, 1);
     if (kok)
