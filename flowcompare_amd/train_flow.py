@@ -17,6 +17,7 @@ AffineCoupling or ExponentialCoupling (latent_dim - latent_dim // 2 <= 16, as in
 first-batch init; LinearLU, random_permute, FullCombiner, ExponentialCombiner; extra context.
 """
 import math
+import os
 
 import torch
 import torch.utils.checkpoint
@@ -262,7 +263,7 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
     # Activation budget: HBM is 288 GB and one layer's saved activations are ~2.6 GB at 16 x 4096 points, so a good part of the stack
     # can simply keep them; only the layers beyond the budget are checkpointed (recomputed in backward).  The first kept layer is
     # measured (allocator growth) and that figure plans the rest.
-    budget, kept_bytes, layer_bytes = 0, 0, None
+    budget, kept_bytes, layer_bytes, n_kept, n_ckpt = 0, 0, None, 0, 0
     if checkpoint and torch.is_grad_enabled() and x.is_cuda:
         if activation_budget_bytes is None:
             activation_budget_bytes = ACTIVATION_BUDGET_BYTES
@@ -322,9 +323,14 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
                 grown = torch.cuda.memory_allocated(x.device) - before
                 layer_bytes = grown if layer_bytes is None else max(layer_bytes, grown)
                 kept_bytes += grown
+                n_kept += 1
         else:
+            n_ckpt += 1
             x1, x2, logp = torch.utils.checkpoint.checkpoint(fn, x1, x2, logp, ctx_panel, extra_panel, e, use_reentrant=False)
 
+    if budget > 0 and os.environ.get("FC_TRAIN_DEBUG"):
+        print(f"[train_flow] activation budget {budget / 2**30:.1f} GiB, kept {kept_bytes / 2**30:.1f} GiB, largest layer {(layer_bytes or 0) / 2**30:.2f} GiB, {n_kept} layers kept / {n_ckpt} recomputed in backward, "
+              f"allocated {torch.cuda.memory_allocated(x.device) / 2**30:.1f} GiB", flush=True)
     # ---- base density (models/distributions.py:192-195)
     logp = logp + T.base_density(x1, rows, d1) + T.base_density(x2, rows, d2)
     return logp[:rows].reshape(B, N)
