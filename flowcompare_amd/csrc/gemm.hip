@@ -706,11 +706,12 @@ void gemm_f32_kernel(const GemmParams p) {
         float omax = 0.f;
         // 64-bit bases once per wave, 32-bit offsets inside the tile (a size_t product per element cost two 64-bit multiply-adds each)
         float* const cbase = e.C ? e.C + (size_t)wave_m0 * e.ldc + wave_n0 : nullptr;
+        float* const pbase = e.Cpre ? e.Cpre + (size_t)wave_m0 * e.ldc + wave_n0 : nullptr;
         const int rp16 = (p.N_pad >> 4) * 32;                          // ushorts per row of the limb image
         unsigned short* const hbase = e.C16 ? e.C16 + (size_t)wave_m0 * rp16 + (size_t)(wave_n0 >> 4) * 32 : nullptr;
         auto body = [&](auto act_tag, auto fmt_tag) {
             constexpr int ACT = decltype(act_tag)::value;
-            constexpr int FMT = decltype(fmt_tag)::value;             // 1: fp32 C, 2: limb image C16, 3: both
+            constexpr int FMT = decltype(fmt_tag)::value;             // 1: fp32 C, 2: limb image C16, 3: both; 5: fp32 C + the pre-activation value in Cpre
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (j < nvalid) {
@@ -723,6 +724,7 @@ void gemm_f32_kernel(const GemmParams p) {
                         for (int r = 0; r < 16; ++r) {
                             const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // row inside the wave's strip
                             float v = acc[i][j][r];
+                            if constexpr ((FMT & 4) != 0) pbase[rl * e.ldc + cl] = v;
                             if constexpr (ACT == FC_ACT_GELU) v = fc_gelu(v);
                             else if constexpr (ACT == FC_ACT_RELU) v = v > 0.f ? v : 0.f;
                             else if constexpr (ACT == FC_ACT_ELU) v = v > 0.f ? v : expm1f(v);
@@ -747,7 +749,8 @@ void gemm_f32_kernel(const GemmParams p) {
             }
         };
         auto by_fmt = [&](auto act_tag) {
-            if (e.C && e.C16) body(act_tag, std::integral_constant<int, 3>{});
+            if (e.Cpre) body(act_tag, std::integral_constant<int, 5>{});         // (the launcher admits Cpre only beside C, without C16)
+            else if (e.C && e.C16) body(act_tag, std::integral_constant<int, 3>{});
             else if (e.C16) body(act_tag, std::integral_constant<int, 2>{});
             else body(act_tag, std::integral_constant<int, 1>{});
         };
@@ -1414,6 +1417,7 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     const bool f16 = v_variant == 5 && L.W2 != nullptr && t_fp16_flag != nullptr;
     if (epi_kind == EPI_LINEAR) {
         if ((!e.C && !e.C16) || (e.C && e.ldc < L.N_pad)) throw Error(FC_ERR_INVALID, "launch_gemm: output pitch smaller than N_pad");
+        if (e.Cpre && (!e.C || e.C16)) throw Error(FC_ERR_INVALID, "launch_gemm: a pre-activation output goes with an fp32 C and no limb image");
         if (e.C16 && !(f16 && v_bigtile == 3 && L.N_pad > 64 && L.N_pad % 16 == 0))
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: limb-image output exists on the eight-wave split-fp16 tile only");
         if (e.A16) {

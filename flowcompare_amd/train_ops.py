@@ -11,6 +11,7 @@ different host threads under autograd); `guard.overflowed()` after backward tell
 `step_guard(fp16=False)` (fp32-input MFMA loop, any range).  Without a guard the fp32-input loop runs.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -18,6 +19,7 @@ import torch
 from . import engine
 
 ROW_PAD = 256
+FUSED_ACT = os.environ.get("FC_TRAIN_FUSED_ACT", "1") != "0"       # 0: activation as its own pass behind the Linear (A/B runs)
 ACT_IDS = {None: 0, "none": 0, "GELU": 1, "RELU": 2, "ELU": 3}
 
 
@@ -150,14 +152,20 @@ class LinearActFn(torch.autograd.Function):
             ldx = _segs([x.shape[1] for x in xs])
             if residual is not None:
                 _check_panel(residual, N)
-            engine._check(L.fc_train_linear_fwd_f32(engine._ptr(pack), N, segs, len(widths), _ptr_array(xs), ldx, rows_pad,
-                                                    engine._ptr(residual), 0 if residual is None else residual.shape[1],
-                                                    engine._ptr(u), N_pad, _flag_ptr(), s))
-            if act:
+            if FUSED_ACT and act in (1, 2, 3):                    # GELU / RELU / ELU: u and y = act(u) from the GEMM's epilogue, one launch
                 y = torch.empty_like(u)
-                engine._check(L.fc_train_act_fwd_f32(engine._ptr(u), engine._ptr(y), rows_pad, N_pad, act, s))
+                engine._check(L.fc_train_linear_act_fwd_f32(engine._ptr(pack), N, segs, len(widths), _ptr_array(xs), ldx, rows_pad,
+                                                            engine._ptr(residual), 0 if residual is None else residual.shape[1],
+                                                            engine._ptr(u), engine._ptr(y), N_pad, act, _flag_ptr(), s))
             else:
-                y = u
+                engine._check(L.fc_train_linear_fwd_f32(engine._ptr(pack), N, segs, len(widths), _ptr_array(xs), ldx, rows_pad,
+                                                        engine._ptr(residual), 0 if residual is None else residual.shape[1],
+                                                        engine._ptr(u), N_pad, _flag_ptr(), s))
+                if act:
+                    y = torch.empty_like(u)
+                    engine._check(L.fc_train_act_fwd_f32(engine._ptr(u), engine._ptr(y), rows_pad, N_pad, act, s))
+                else:
+                    y = u
         ctx.save_for_backward(pack, u if act else None, *xs)
         ctx.meta = (N, K, tuple(widths), act, rows, bias is not None, residual is not None, weight.dtype)
         return y

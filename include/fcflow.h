@@ -21,7 +21,7 @@
  *     interpolation), LeakyReLU slope argument of fc_train_edge_fwd_f32 / fc_train_edge_bwd_prep_f32 (0 = ReLU), optimiser step
  *     (fc_train_sqnorm_f32, fc_train_adam_f32);
  * 5 = + the deferred range check (fc_range_check_defer / _resolve / _pending);
- * 6 = + fc_profile_stride (sampled bracketing of the in-library kernel timing).
+ * 6 = + fc_profile_stride (sampled bracketing of the in-library kernel timing), fc_train_linear_act_fwd_f32 (activation in the GEMM epilogue).
  */
 #ifndef FCFLOW_H
 #define FCFLOW_H
@@ -248,6 +248,11 @@ int fc_train_linear_pack_f32(const float* W, const float* bias, int32_t N, const
 /* u [rows_pad, ldu] = cat(x...) W^T + bias (+ residual): the pre-activation, which the backward needs. */
 int fc_train_linear_fwd_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* const* x, const int32_t* ldx,
                             int32_t rows_pad, const float* residual, int32_t ldr, float* u, int32_t ldu, int32_t* ovf, void* stream);
+/* The same with the activation applied in the GEMM's epilogue: u (pre-activation, what the backward of the activation reads) and
+ * y = act(u) (FC_ACT_GELU / _RELU / _ELU) from ONE launch, both with pitch ldu.  ABI v6. */
+int fc_train_linear_act_fwd_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* const* x, const int32_t* ldx,
+                                int32_t rows_pad, const float* residual, int32_t ldr, float* u, float* y, int32_t ldu, int32_t act, int32_t* ovf,
+                                void* stream);
 /* dx [rows_pad, lddx >= sum of padded segment widths] = du W  (columns in padded-segment order). */
 int fc_train_linear_dgrad_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu,
                               int32_t rows_pad, float* dx, int32_t lddx, int32_t* ovf, void* stream);
