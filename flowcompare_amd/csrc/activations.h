@@ -82,6 +82,21 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
+// d act / du (training: fc_train_act_bwd_f32 and the activation-gradient epilogue of the data-gradient GEMM); GELU = exact erf form
+__device__ __forceinline__ float fc_act_grad(float u, int act) {
+    switch (act) {
+        case FC_ACT_GELU: {
+            // d/du [u Phi(u)] = Phi(u) + u phi(u)
+            const float cdf = 0.5f * erfcf(-u * 0.70710678118654752440f);
+            return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+        }
+        case FC_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+        case FC_ACT_ELU: return u > 0.f ? 1.f : expf(u);
+        case FC_ACT_LRELU02: return u > 0.f ? 1.f : 0.2f;
+        default: return 1.f;
+    }
+}
+
 __device__ __forceinline__ float half_wave_sum(float v) {
     // sum over the 32 lanes that share (lane>>5): xor masks < 32 never cross the half
     v += __shfl_xor(v, 1, 64);

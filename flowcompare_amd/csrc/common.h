@@ -134,6 +134,7 @@ struct GemmEpi {
     const unsigned short* residual16 = nullptr; int ldr16 = 0;   // the residual given as an fp16 limb image [rows][ldr16/16][hi 16 | lo' 16] (x = hi + lo'/2048)
     const float* rowscal = nullptr;          // [rows] (extra context per point), used with PackedLinear.colvec
     float* C = nullptr; int ldc = 0;          // may be null when only the limb image C16 is wanted
+    const float* gradu = nullptr; int ldgu = 0; int gact = FC_ACT_NONE;   // LINEAR, optional (training data gradient): C = value * act'(gradu[row][col]) for gact
     float* Cpre = nullptr;                    // LINEAR, optional (training forward): the PRE-activation value goes here (pitch ldc), act(value) to C
     unsigned short* C16 = nullptr;            // optional: the output as fp16 limb image [rows][N_pad/16][hi 16 | lo' 16] (operand image of a
                                               // following split-fp16 GEMM, which then copies it instead of re-splitting it per column tile)

@@ -706,11 +706,14 @@ void gemm_f32_kernel(const GemmParams p) {
         float omax = 0.f;
         // 64-bit bases once per wave, 32-bit offsets inside the tile (a size_t product per element cost two 64-bit multiply-adds each)
         float* const cbase = e.C ? e.C + (size_t)wave_m0 * e.ldc + wave_n0 : nullptr;
+        // the training epilogues (pre-activation copy, activation gradient) exist on the fp32-A loops only -- the ones the fc_train_* entries launch
+        constexpr bool TRAIN_EPI = VAR == 2 || VAR == 3 || VAR == 5;
         float* const pbase = e.Cpre ? e.Cpre + (size_t)wave_m0 * e.ldc + wave_n0 : nullptr;
+        const float* const gbase = e.gradu ? e.gradu + (size_t)wave_m0 * e.ldgu + wave_n0 : nullptr;
         const int rp16 = (p.N_pad >> 4) * 32;                          // ushorts per row of the limb image
         unsigned short* const hbase = e.C16 ? e.C16 + (size_t)wave_m0 * rp16 + (size_t)(wave_n0 >> 4) * 32 : nullptr;
         auto body = [&](auto act_tag, auto fmt_tag) {
-            constexpr int ACT = decltype(act_tag)::value;
+            constexpr int ACT = decltype(act_tag)::value;             // 16 + a: no activation, the value is multiplied by act_a'(gradu[row][col]) instead
             constexpr int FMT = decltype(fmt_tag)::value;             // 1: fp32 C, 2: limb image C16, 3: both; 5: fp32 C + the pre-activation value in Cpre
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -718,12 +721,20 @@ void gemm_f32_kernel(const GemmParams p) {
                     const int cl = j * 32 + li;                       // column inside the wave's strip
                     const int c0 = cl & ~1;
                     const int hoff = (c0 >> 4) * 32 + ((li & 1) ? 16 : 0) + (c0 & 15);
+                    float gu[ACT >= 16 ? TM : 1][16];                 // the block's act' arguments, requested up front (independent loads)
+                    if constexpr (ACT >= 16) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) gu[i][r] = gbase[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * e.ldgu + cl];
+                    }
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // row inside the wave's strip
                             float v = acc[i][j][r];
+                            if constexpr (ACT >= 16) v *= fc_act_grad(gu[i][r], ACT - 16);
                             if constexpr ((FMT & 4) != 0) pbase[rl * e.ldc + cl] = v;
                             if constexpr (ACT == FC_ACT_GELU) v = fc_gelu(v);
                             else if constexpr (ACT == FC_ACT_RELU) v = v > 0.f ? v : 0.f;
@@ -749,11 +760,23 @@ void gemm_f32_kernel(const GemmParams p) {
             }
         };
         auto by_fmt = [&](auto act_tag) {
-            if (e.Cpre) body(act_tag, std::integral_constant<int, 5>{});         // (the launcher admits Cpre only beside C, without C16)
-            else if (e.C && e.C16) body(act_tag, std::integral_constant<int, 3>{});
+            if constexpr (TRAIN_EPI) { if (e.Cpre) { body(act_tag, std::integral_constant<int, 5>{}); return; } }   // (the launcher admits Cpre only beside C, without C16)
+            if (e.C && e.C16) body(act_tag, std::integral_constant<int, 3>{});
             else if (e.C16) body(act_tag, std::integral_constant<int, 2>{});
             else body(act_tag, std::integral_constant<int, 1>{});
         };
+        bool grad_done = false;
+        if constexpr (TRAIN_EPI) {
+            if (e.gradu) {                                           // (the launcher admits it with an fp32 C only and no activation)
+                switch (e.gact) {
+                    case FC_ACT_GELU: body(std::integral_constant<int, 16 + FC_ACT_GELU>{}, std::integral_constant<int, 1>{}); break;
+                    case FC_ACT_RELU: body(std::integral_constant<int, 16 + FC_ACT_RELU>{}, std::integral_constant<int, 1>{}); break;
+                    default: body(std::integral_constant<int, 16 + FC_ACT_ELU>{}, std::integral_constant<int, 1>{}); break;
+                }
+                grad_done = true;
+            }
+        }
+        if (!grad_done)
         switch (e.act) {
             case FC_ACT_GELU: by_fmt(std::integral_constant<int, FC_ACT_GELU>{}); break;
             case FC_ACT_RELU: by_fmt(std::integral_constant<int, FC_ACT_RELU>{}); break;
@@ -1417,6 +1440,9 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
     const bool f16 = v_variant == 5 && L.W2 != nullptr && t_fp16_flag != nullptr;
     if (epi_kind == EPI_LINEAR) {
         if ((!e.C && !e.C16) || (e.C && e.ldc < L.N_pad)) throw Error(FC_ERR_INVALID, "launch_gemm: output pitch smaller than N_pad");
+        if ((e.gradu || e.Cpre) && e.A16) throw Error(FC_ERR_INVALID, "launch_gemm: the training epilogues exist on the fp32-A loops only");
+        if (e.gradu && (!e.C || e.C16 || e.Cpre || e.act != FC_ACT_NONE || e.ldgu < L.N_pad || (e.gact != FC_ACT_GELU && e.gact != FC_ACT_RELU && e.gact != FC_ACT_ELU)))
+            throw Error(FC_ERR_INVALID, "launch_gemm: an activation-gradient epilogue goes with an fp32 C, no activation, and GELU / RELU / ELU");
         if (e.Cpre && (!e.C || e.C16)) throw Error(FC_ERR_INVALID, "launch_gemm: a pre-activation output goes with an fp32 C and no limb image");
         if (e.C16 && !(f16 && v_bigtile == 3 && L.N_pad > 64 && L.N_pad % 16 == 0))
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: limb-image output exists on the eight-wave split-fp16 tile only");

@@ -29,7 +29,7 @@ EXPORTS = [
     "fc_profile_enable", "fc_profile_reset", "fc_profile_filter", "fc_profile_stride", "fc_profile_report",
     "fc_op_linear_f32", "fc_op_mlp_hidden_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
     "fc_stage_fps_f32", "fc_stage_co_unit_sphere_f32", "fc_clamp_infs_f32", "fc_change_map_f32",
-    "fc_train_linear_pack_bytes", "fc_train_linear_pack_f32", "fc_train_linear_fwd_f32", "fc_train_linear_act_fwd_f32", "fc_train_linear_dgrad_f32",
+    "fc_train_linear_pack_bytes", "fc_train_linear_pack_f32", "fc_train_linear_fwd_f32", "fc_train_linear_act_fwd_f32", "fc_train_linear_dgrad_f32", "fc_train_linear_dgrad_act_f32",
     "fc_train_linear_wgrad_ws_bytes", "fc_train_linear_wgrad_f32", "fc_train_act_fwd_f32", "fc_train_act_bwd_f32",
     "fc_train_attention_ws_bytes", "fc_train_attention_fwd_f32", "fc_train_attention_bwd_f32",
     "fc_train_rqspline_fwd_f32", "fc_train_rqspline_bwd_f32", "fc_train_layernorm_fwd_f32", "fc_train_layernorm_bwd_f32",

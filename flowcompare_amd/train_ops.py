@@ -221,8 +221,132 @@ def linear_act(xs, widths, weight, bias, rows, act=None, residual=None):
     return LinearActFn.apply(weight, bias, residual, ACT_IDS[act] if not isinstance(act, int) else act, rows, tuple(widths), *xs)
 
 
+class MlpFn(torch.autograd.Function):
+    """The whole residual MLP of models/nets.py:19-30 as ONE autograd node (same kernels as a chain of LinearActFn nodes in forward).  Its
+    backward walks the layers itself, so the data gradient of layer l + 1 can leave the GEMM already multiplied by act'(u_l) and with the
+    residual branch's gradient added (fc_train_linear_dgrad_act_f32): no activation-backward pass and no gradient adds between the layers.
+    Arguments: rows, act id, widths of the input panels, their count, then the input panels, then (weight, bias) of in_layer, the hidden
+    layers and out_layer."""
+
+    @staticmethod
+    def forward(ctx, rows, act, widths, nx, *t):
+        L = engine.lib()
+        xs, params = t[:nx], t[nx:]
+        nl = len(params) // 2
+        for x, w in zip(xs, widths):
+            _check_panel(x, w)
+        rows_pad, dev = xs[0].shape[0], xs[0].device
+        packs, us, ys, metas = [], [], [], []
+        cur, cur_w, keep = list(xs), list(widths), None
+        with _OnDevice(dev):
+            s = engine._stream()
+            for l in range(nl):
+                W, b = params[2 * l], params[2 * l + 1]
+                N, K = W.shape
+                if sum(cur_w) != K:
+                    raise RuntimeError(f"MlpFn: layer {l} reads {K} features, its input panels hold {cur_w}")
+                w32 = W.detach().to(torch.float32).contiguous()
+                b32 = None if b is None else b.detach().to(torch.float32).contiguous()
+                segs = _segs(cur_w)
+                N_pad = _round_up(N, 32)
+                nb = L.fc_train_linear_pack_bytes(N, segs, len(cur_w))
+                pack = torch.empty(nb, dtype=torch.uint8, device=dev)
+                engine._check(L.fc_train_linear_pack_f32(engine._ptr(w32), engine._ptr(b32), N, segs, len(cur_w), engine._ptr(pack),
+                                                         ctypes.c_size_t(nb), _flag_ptr(), s))
+                h = l - 1                                             # hidden index: even -> keep = input, odd -> residual = keep
+                last = l == nl - 1
+                residual = keep if (0 < l < nl - 1 and h % 2 == 1) else None
+                if 0 < l < nl - 1 and h % 2 == 0:
+                    keep = cur[0]
+                u = torch.empty(rows_pad, N_pad, dtype=torch.float32, device=dev)
+                ldx = _segs([x.shape[1] for x in cur])
+                if last:
+                    engine._check(L.fc_train_linear_fwd_f32(engine._ptr(pack), N, segs, len(cur_w), _ptr_array(cur), ldx, rows_pad,
+                                                            None, 0, engine._ptr(u), N_pad, _flag_ptr(), s))
+                    y = u
+                else:
+                    y = torch.empty_like(u)
+                    engine._check(L.fc_train_linear_act_fwd_f32(engine._ptr(pack), N, segs, len(cur_w), _ptr_array(cur), ldx, rows_pad,
+                                                                engine._ptr(residual), 0 if residual is None else residual.shape[1],
+                                                                engine._ptr(u), engine._ptr(y), N_pad, act, _flag_ptr(), s))
+                packs.append(pack); us.append(None if last else u); ys.append(y)
+                metas.append((N, K, tuple(cur_w), b is not None, W.dtype))
+                cur, cur_w = [y], [N]
+        ctx.save_for_backward(*xs, *packs, *[u for u in us if u is not None], *ys[:-1])
+        ctx.meta = (rows, act, tuple(widths), nx, nl, metas)
+        return ys[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = engine.lib()
+        rows, act, widths, nx, nl, metas = ctx.meta
+        sv = ctx.saved_tensors
+        xs, packs = sv[:nx], sv[nx:nx + nl]
+        us, ys = sv[nx + nl:nx + nl + nl - 1], sv[nx + 2 * nl - 1:]
+        dev = dy.device
+        rows_pad = xs[0].shape[0]
+        need = ctx.needs_input_grad
+        grads = [None] * (4 + nx + 2 * nl)
+        du = dy.contiguous()                                             # out_layer has no activation
+        du_next = None                                                   # du of layer l + 1 (the residual branch's gradient when l is an even hidden layer)
+        with _OnDevice(dev):
+            s = engine._stream()
+            for l in range(nl - 1, -1, -1):
+                N, K, in_w, has_bias, wdtype = metas[l]
+                N_pad = _round_up(N, 32)
+                ins = list(xs) if l == 0 else [ys[l - 1]]
+                segs = _segs(in_w)
+                ldx = _segs([x.shape[1] for x in ins])
+                wi = 4 + nx + 2 * l
+                if need[wi] or (has_bias and need[wi + 1]):
+                    nb = L.fc_train_linear_wgrad_ws_bytes(N, segs, len(in_w), rows)
+                    ws = _ws(nb, dev)
+                    dW = torch.empty(N, K, dtype=torch.float32, device=dev) if need[wi] else None
+                    db = torch.empty(N, dtype=torch.float32, device=dev) if (has_bias and need[wi + 1]) else None
+                    engine._check(L.fc_train_linear_wgrad_f32(N, segs, len(in_w), engine._ptr(du), N_pad, _ptr_array(ins), ldx, rows,
+                                                              engine._ptr(dW), engine._ptr(db), 0, engine._ptr(ws), ctypes.c_size_t(nb), _flag_ptr(), s))
+                    grads[wi] = None if dW is None else dW.to(wdtype)
+                    grads[wi + 1] = db
+                if l == 0:
+                    if any(need[4:4 + nx]):
+                        K_pad = sum(_round_up(w, 32) for w in in_w)
+                        dx = torch.empty(rows_pad, K_pad, dtype=torch.float32, device=dev)
+                        engine._check(L.fc_train_linear_dgrad_f32(engine._ptr(packs[0]), N, segs, len(in_w), engine._ptr(du), N_pad, rows_pad,
+                                                                  engine._ptr(dx), K_pad, _flag_ptr(), s))
+                        off = 0
+                        for i, (x, w) in enumerate(zip(xs, in_w)):
+                            wp = _round_up(w, 32)
+                            if need[4 + i]:
+                                g = dx[:, off:off + wp]
+                                if x.shape[1] != wp:
+                                    g = torch.nn.functional.pad(g, (0, x.shape[1] - wp))
+                                grads[4 + i] = g
+                            off += wp
+                    break
+                # gradient w.r.t. the previous layer's pre-activation: (du . W + [residual branch]) * act'(u_{l-1})
+                h = l - 1
+                addend = du_next if (l < nl - 1 and h % 2 == 0 and l + 1 < nl - 1) else None
+                K_pad = _round_up(K, 32)
+                du_prev = torch.empty(rows_pad, K_pad, dtype=torch.float32, device=dev)
+                engine._check(L.fc_train_linear_dgrad_act_f32(engine._ptr(packs[l]), N, segs, 1, engine._ptr(du), N_pad, rows_pad,
+                                                              engine._ptr(du_prev), K_pad, engine._ptr(addend), engine._ptr(us[l - 1]), act,
+                                                              _flag_ptr(), s))
+                du_next, du = du, du_prev
+        return tuple(grads)
+
+
+FUSED_MLP = os.environ.get("FC_TRAIN_FUSED_MLP", "1") != "0"       # 0: the MLP as a chain of LinearActFn nodes (A/B runs, and any activation MlpFn does not take)
+
+
 def mlp_panels(mlp, xs, widths, rows, act):
     """models/nets.py:19-30 on panels: act(in) ; even hidden layer: r = x, x = act(W x) ; odd: x = act(r + W x) ; out (no activation)."""
+    act_id = ACT_IDS[act] if not isinstance(act, int) else act
+    if FUSED_MLP and FUSED_ACT and act_id in (1, 2, 3) and all(l.in_features % 32 == 0 for l in list(mlp.layers) + [mlp.out_layer]):
+        params = [mlp.in_layer.weight, mlp.in_layer.bias]
+        for layer in mlp.layers:
+            params += [layer.weight, layer.bias]
+        params += [mlp.out_layer.weight, mlp.out_layer.bias]
+        return MlpFn.apply(rows, act_id, tuple(widths), len(xs), *xs, *params)
     x = linear_act(xs, widths, mlp.in_layer.weight, mlp.in_layer.bias, rows, act)
     keep = None
     for i, layer in enumerate(mlp.layers):

@@ -21,7 +21,7 @@
  *     interpolation), LeakyReLU slope argument of fc_train_edge_fwd_f32 / fc_train_edge_bwd_prep_f32 (0 = ReLU), optimiser step
  *     (fc_train_sqnorm_f32, fc_train_adam_f32);
  * 5 = + the deferred range check (fc_range_check_defer / _resolve / _pending);
- * 6 = + fc_profile_stride (sampled bracketing of the in-library kernel timing), fc_train_linear_act_fwd_f32 (activation in the GEMM epilogue).
+ * 6 = + fc_profile_stride (sampled bracketing of the in-library kernel timing), fc_train_linear_act_fwd_f32 / fc_train_linear_dgrad_act_f32 (activation and its backward in the GEMM epilogues).
  */
 #ifndef FCFLOW_H
 #define FCFLOW_H
@@ -256,6 +256,11 @@ int fc_train_linear_act_fwd_f32(const void* pack, int32_t N, const int32_t* seg_
 /* dx [rows_pad, lddx >= sum of padded segment widths] = du W  (columns in padded-segment order). */
 int fc_train_linear_dgrad_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu,
                               int32_t rows_pad, float* dx, int32_t lddx, int32_t* ovf, void* stream);
+/* Data gradient of a hidden Linear fused with the backward of the activation in front of it:
+ * dx = (du . W + addend) * act'(u_prev), i.e. the gradient w.r.t. the previous layer's PRE-activation (addend: optional gradient of a
+ * residual branch that joins at the previous layer's output; u_prev / addend / dx are [rows_pad, lddx] panels; one input segment).  ABI v6. */
+int fc_train_linear_dgrad_act_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu, int32_t rows_pad,
+                                  float* dx, int32_t lddx, const float* addend, const float* u_prev, int32_t act, int32_t* ovf, void* stream);
 size_t fc_train_linear_wgrad_ws_bytes(int32_t N, const int32_t* seg_widths, int32_t nseg, int32_t rows);
 /* dW [N,K] (=|+=) du[:rows]^T cat(x...)[:rows],  db [N] (=|+=) column sums of du[:rows]; either may be NULL.  fp32-input MFMA,
  * fixed summation order (bit-reproducible).  ws: 256-byte aligned scratch of fc_train_linear_wgrad_ws_bytes. */

@@ -96,6 +96,35 @@ def test_mlp_at_coupling_widths_matches_oracle_autograd(act):
     assert max(errs.values()) < 2e-5, errs
 
 
+def test_fused_mlp_node_agrees_with_the_chain_of_linear_nodes(monkeypatch):
+    """MlpFn (one autograd node; activation in the forward GEMM's epilogue, act' and the residual branch's gradient in the data-gradient
+    GEMM's) against the same MLP as a chain of LinearActFn nodes with separate activation passes: same forward bits, gradients to
+    fp32 rounding (the fused data gradient adds the residual branch before the products instead of after them).  Four hidden layers:
+    keep / residual / keep / residual, so both kinds of hidden layer occur with and without a following residual."""
+    torch.manual_seed(5)
+    mlp = M.MLP(182, [512, 512, 512, 512, 512], 96).to(DEV)
+    rows = 900
+    g = torch.Generator().manual_seed(6)
+    x1, c = torch.randn(rows, 150, generator=g).to(DEV), torch.randn(rows, 32, generator=g).to(DEV)
+    dy = torch.randn(rows, 96, generator=g).to(DEV)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(T, "FUSED_MLP", fused)
+        monkeypatch.setattr(T, "FUSED_ACT", fused)
+        mlp.zero_grad()
+        a, b = x1.clone().requires_grad_(True), c.clone().requires_grad_(True)
+        with T.step_guard(device=DEV) as guard:
+            y = T.from_panel(T.mlp_panels(mlp, [T.to_panel(a), T.to_panel(b)], [150, 32], rows, "GELU"), rows, 96)
+            y.backward(dy)
+            assert not guard.overflowed()
+        out[fused] = (y.detach().clone(), a.grad.clone(), b.grad.clone(), [p.grad.clone() for p in mlp.parameters()])
+    assert torch.equal(out[True][0], out[False][0])
+    worst = max(_rel(out[True][1], out[False][1].double().cpu()), _rel(out[True][2], out[False][2].double().cpu()),
+                max(_rel(p, q.double().cpu()) for p, q in zip(out[True][3], out[False][3])))
+    print(f"fused MLP node vs chain of nodes: worst relative gradient difference {worst:.1e}")
+    assert worst < 2e-6
+
+
 def test_mlp_forward_on_plain_tensors_and_range_guard():
     torch.manual_seed(8)
     mlp = M.MLP(6, [64, 64, 64], 32).to(DEV)
