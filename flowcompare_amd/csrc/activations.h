@@ -82,14 +82,34 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     }
 }
 
+// d/dv [v Phi(v)] = Phi(v) + v phi(v) on fc_gelu's machinery: Phi(-|v|) = erfc(u) / 2 from the same fit, phi(v) = exp2(-u^2 log2 e) / sqrt(2 pi)
+// with the same (clamped) u.  ~24 VALU instructions where erfcf + expf compile to ~60 (the epilogue of the training data-gradient GEMM evaluates
+// it for every output value); |error| <= 2.3e-7 against fp64 on [-9, 9].
+__device__ __forceinline__ float fc_gelu_grad(float v) {
+    const float u = fminf(fabsf(v) * 0.70710678118654752440f, 5.2f);
+    float g = 3.599303965984291e-08f;
+    g = fmaf(g, u, -1.1551159104783437e-06f);
+    g = fmaf(g, u, 1.6193846022360958e-05f);
+    g = fmaf(g, u, -0.00012855215754825622f);
+    g = fmaf(g, u, 0.0006109004025347531f);
+    g = fmaf(g, u, -0.0014898879453539848f);
+    g = fmaf(g, u, -0.00129302020650357f);
+    g = fmaf(g, u, 0.02910642884671688f);
+    g = fmaf(g, u, -0.14908140897750854f);
+    g = fmaf(g, u, 0.5244691371917725f);
+    g = fmaf(g, u, -1.627930760383606f);
+    g = fmaf(g, u, 4.18458824924528e-07f - 1.0f);
+    const float t = -1.4426950408889634f * u * u;
+    const float e = __builtin_amdgcn_exp2f(t + g);                                    // Phi(-|v|)
+    const float p = __builtin_amdgcn_exp2f(t);                                        // exp(-v^2 / 2)
+    const float cdf = 0.5f + copysignf(0.5f - e, v);                                  // Phi(v)
+    return fmaf(v, 0.39894228040143267794f * p, cdf);
+}
+
 // d act / du (training: fc_train_act_bwd_f32 and the activation-gradient epilogue of the data-gradient GEMM); GELU = exact erf form
 __device__ __forceinline__ float fc_act_grad(float u, int act) {
     switch (act) {
-        case FC_ACT_GELU: {
-            // d/du [u Phi(u)] = Phi(u) + u phi(u)
-            const float cdf = 0.5f * erfcf(-u * 0.70710678118654752440f);
-            return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
-        }
+        case FC_ACT_GELU: return fc_gelu_grad(u);
         case FC_ACT_RELU: return u > 0.f ? 1.f : 0.f;
         case FC_ACT_ELU: return u > 0.f ? 1.f : expf(u);
         case FC_ACT_LRELU02: return u > 0.f ? 1.f : 0.2f;
