@@ -10,8 +10,9 @@ batch that is already resident in HBM.  Workload at N=1: BASELINE.json configs[1
 quadratic spline coupling, batch 16, 4096 target + 4096 context points).  For N > 1 every rank runs the same per-GPU batch on
 its own scenes (scenes are independent: no data-path collective; weak scaling); the global loss is one scalar all-reduce.
 
-Prints ONE JSON line on rank 0, with `roofline` (dominant kernel: its launches are bracketed by HIP events inside the library
-over the timed region; the other kernels are only bracketed in the last warmup step, which yields the `kernels` breakdown --
+Prints ONE JSON line on rank 0, with `roofline` (dominant kernel: a sample of its launches -- every n-th, about 32 per step --
+is bracketed by HIP events inside the library over the timed region; the other kernels are only bracketed in the last warmup step,
+which yields the `kernels` breakdown --
 bracketing every launch of the timed region costs 3 % of the throughput) and `cpu_baseline` (the pinned CPU oracle timed on the
 host cores on a bounded sample of the same workload).
 """
