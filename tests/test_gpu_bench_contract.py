@@ -27,7 +27,7 @@ def test_bench_prints_one_json_line_with_roofline_cpu_baseline_and_train():
     assert j["unit"] == "nats/sec" and j["value"] > 0 and abs(j["value"] - 2 * 256 / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
     assert "workload" in j["config"] and "model" not in j["config"]
     roof = j["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches", "launches_bracketed"):
         assert k in roof, k
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     if "frac_issued" in roof:

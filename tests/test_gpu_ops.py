@@ -323,3 +323,21 @@ def test_knn_with_non_finite_features_returns_valid_indices(knn_kernel):
     f[1, 7] = float("inf")
     idx = engine.op_knn(f.to(DEV), 40).cpu().long()
     assert idx.min() >= 0 and idx.max() < 300
+
+
+def test_profile_stride_brackets_every_nth_matching_launch():
+    """fc_profile_stride (ABI v6): of the launches that pass the filter every n-th one is bracketed; the report counts the bracketed ones."""
+    x, W = torch.randn(256, 64).to(DEV), torch.randn(64, 64).to(DEV)
+    counts = {}
+    for stride in (1, 4):
+        engine.profile_filter("gemm_f32_kernel"); engine.profile_stride(stride); engine.profile_reset(); engine.profile_enable(True)
+        for _ in range(10):
+            engine.op_linear(x, W)
+        torch.cuda.synchronize()
+        engine.profile_enable(False)
+        rep = engine.profile_report()
+        counts[stride] = sum(p["launches"] for p in rep if "gemm_f32_kernel" in p["kernel"])
+        assert all(p["ms"] > 0 for p in rep)
+    engine.profile_filter(None); engine.profile_stride(1); engine.profile_reset()
+    assert counts[1] == 10 and counts[4] == 3, counts          # launches 0, 4, 8
+
