@@ -346,7 +346,7 @@ def main():
         if dom["flops"] > 0:
             useful = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12          # fp32-equivalent multiply-add TFLOP/s
             var = next((v for v in SPLIT_MFMA_PER_PRODUCT if dom["kernel"].endswith(f", {v}>(fc::GemmParams)")), None)   # ..., VAR>
-            if var is None and any(k in dom["kernel"] for k in ("attn16_kernel", "mlp_rows_kernel", "premlp_rows_kernel", "premlp_kernel")):
+            if var is None and any(k in dom["kernel"] for k in ("attn16_kernel", "mlp_rows_kernel", "premlp_rows_kernel", "premlp_kernel", "spline_wide_kernel")):
                 var = 5                                     # split-fp16 attention / row-resident MLP chains: 3 limb products per fp32-equivalent product
             # achieved = ALGORITHMIC fp32-equivalent FLOPs of the launches / their time, against the dense 16-bit MFMA peak the
             # loop runs on.  The split loops issue n limb products per fp32-equivalent product: that issue rate is reported beside it as

@@ -43,6 +43,17 @@ __device__ __forceinline__ void limb_split2(float x0, float x1, unsigned& hi, un
     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(lo) : "v"(d0), "s"(2048.0f));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(lo) : "v"(d1), "s"(2048.0f));
 }
+// The same with run-time (wave-uniform) scales: hi = rn16(x s1), lo = rn16((x s1 - hi) s2).  (1, 2048) gives limb_split2's bits exactly (the
+// products by 1 are exact); (kOneAccActScale, 1) the one-accumulator form of spline_wide.hip (common.h).  Six VALU instructions for the pair.
+__device__ __forceinline__ void limb_split2s(float x0, float x1, float s1, float s2, unsigned& hi, unsigned& lo) {
+    float d0, d1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "s"(s1));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "s"(s1));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(d0) : "v"(x0), "s"(s1), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d1) : "v"(x1), "s"(s1), "v"(hi));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(lo) : "v"(d0), "s"(s2));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(lo) : "v"(d1), "s"(s2));
+}
 // element SEL (0 = low half, 1 = high half) of packed limb words back to fp32, x = hi + lo'/2048, in one v_fma_mix_f32 (the scalar
 // formulation is two converts and a multiply-add); the product is exact, the sum rounds once either way: same bits
 template <int SEL>

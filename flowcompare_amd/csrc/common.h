@@ -39,6 +39,11 @@ void set_last_error(const std::string& m);
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
+// One-accumulator limb form (spline_wide.hip): activations are stored as hi + lo of x * kOneAccActScale with lo = rn16(x s - hi) UNSCALED.  The
+// exact power-of-two pre-scale keeps lo a normal fp16 number for |x| >= 2^-7 (absolute floor 2^-29 below that) and leaves fp16's range at
+// |x| < 4094: a producer that meets more raises the range flag like any other split-fp16 kernel (the pass then repeats on the bf16 limbs).
+constexpr float kOneAccActScale = 16.0f;
+
 constexpr int ROW_PAD = 256;   // row counts of every workspace matrix are padded to this (largest GEMM BM)
 constexpr int COL_PAD = 32;    // feature widths are padded to this (GEMM BK / MFMA tile)
 
@@ -101,6 +106,10 @@ struct PackedLinear {
                                    // (operand image of the split-bf16 GEMM variant, see gemm.hip)
     unsigned short* Wf = nullptr;  // K <= 512 -> 512 layers of a coupling MLP: the fp16 limb image pre-tiled in MFMA-fragment order,
                                    // [N/32][ks][2][64 lanes][8] (mlprows.hip: one LDS-DMA piece = one linear 1 KiB read); null otherwise
+    unsigned short* W1 = nullptr;  // spline parameter layer (K = 8 bins) only: the ONE-ACCUMULATOR fp16 limb image of spline_wide.hip,
+                                   // [round_up(N_pad, 256)][K_pad/16][2][16]: w 2^w1_exp = hi + lo with lo UNSCALED, rows in that kernel's column order
+    float* bias1 = nullptr;        // its bias in the same order, times kOneAccActScale 2^w1_exp
+    int w1_exp = 0;
     int N_pad = 0;             // columns written (multiple of 32)
     int K_pad = 0;             // multiple of 32 (sum of segment widths)
     int seg_k[3] = {0, 0, 0};  // padded K of each A segment
@@ -139,6 +148,8 @@ struct GemmEpi {
     unsigned short* C16 = nullptr;            // optional: the output as fp16 limb image [rows][N_pad/16][hi 16 | lo' 16] (operand image of a
                                               // following split-fp16 GEMM, which then copies it instead of re-splitting it per column tile)
     const unsigned short* A16 = nullptr;      // input: the A operand given as such an image (single segment of K_pad columns)
+    float c16_scale = 0.f;                    // C16 in the one-accumulator form instead: hi + lo of value * c16_scale, lo unscaled (0: the hi + lo'/2048 form)
+    float a16_scale = 0.f;                    // A16 arrives in that form (EPI_SPLINE on spline_wide.hip only)
     // EPI_AFFINE (W pair-packed [s 32 | t 32] x pairs): in-place y2 = x2*s + t on xbuf, logprob[row] += sum log s
     // EPI_AUGMENT (W pair-packed [mu 32 | logsigma 32]): z2 = mu + eps*sigma scattered into xbuf, logprob += -log N(z2)
     float* xbuf = nullptr; int ldx = 0;
@@ -268,8 +279,13 @@ void launch_mlp_rows_image(const PackedLinear& L, unsigned short* Wf, hipStream_
 bool mlp_rows_eligible(const PackedLinear& in, const std::vector<PackedLinear>& mid, int act);
 bool mlp_rows_fills_the_chip(int rows_alloc);           // at least 3/4 of the CUs get a 128-row workgroup
 void launch_mlp_rows(const PackedLinear& in, const std::vector<PackedLinear>& mid, const ASeg* segs, const float* rowscal, int act,
-                     float* const h[3], unsigned short* out16, int rows_alloc, int rows_valid, hipStream_t s);
+                     float* const h[3], unsigned short* out16, int rows_alloc, int rows_valid, hipStream_t s, float out16_scale = 0.f);   // out16_scale: GemmEpi::c16_scale of the last layer
 void launch_limb_decode(const unsigned short* img, float* out, int ldo, int rows, int width, hipStream_t s);   // row-major limb image -> fp32 (tests)
+// spline_wide.hip: the fused spline parameter layer on 256 x 256 tiles with one accumulator per output (K = 8 bins, limb-chained input)
+bool spline_wide_eligible(const PackedLinear& L, int K_bins);
+void spline_wide_attach(DeviceArena& arena, PackedLinear& L, float wmax, hipStream_t s);
+void launch_spline_wide(const PackedLinear& L, const GemmEpi& e, int rows_alloc, hipStream_t s);
+bool gemm_spline_wide_on();      // knob 13 = 5 (shipped): launch_gemm routes eligible EPI_SPLINE launches there
 // staging.hip: the steps either side of the path
 void launch_fps_nd(const float* pts, int ld, int C, int64_t* idx, int B, int n, int m, float* dist_scratch, hipStream_t s);
 void launch_co_unit_sphere(const float* p0, int n0, const float* p1, int n1, int ld, float* o0, float* o1, float* inverse, int B, hipStream_t s);

@@ -318,6 +318,14 @@ static void build_out_layer(fc_flow& f, const WeightTable& wt, const std::string
         nmap = map_prefix(n, round_up(n, 32));
     }
     net.out_layer = pack_linear(f.arena, mat_from(w), b, {}, nmap, map_prefix(hl, round_up(hl, 32)), {round_up(hl, 32)});
+    if (f.cfg.flow_type == FC_FLOW_SPLINE && f.cfg.num_bins_spline == 8) {
+        // the one-accumulator image of the 256 x 256 fused spline kernel (spline_wide.hip): rows in that kernel's register-slot order, pre-scaled by
+        // the power of two that puts max |w| into [2^14, 2^15)
+        float wmax = 0.f;
+        const int64_t nel = w.numel();
+        for (int64_t i = 0; i < nel; ++i) wmax = std::max(wmax, std::fabs(w.data[i]));
+        spline_wide_attach(f.arena, net.out_layer, wmax, nullptr);
+    }
 }
 
 // pair-packed row map from explicit (first-half row, second-half row) lists
@@ -568,16 +576,16 @@ void flow_set_trace(float* buf, size_t floats) { t_flow_trace = buf; t_flow_trac
 int g_premlp_chain = 0;      // knob 19: limb chain through the pre-attention MLP into the LayerNorm -> q GEMM (K = 256: 8 k-tiles per
                              // output tile, the tile-boundary cost of the DMA loop outweighs its main loop: measured 1 % slower end to end)
 static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_segs, const float* rowscal, FlowWs& w, int act, hipStream_t s,
-                          unsigned short* last_limbs = nullptr) {
+                          unsigned short* last_limbs = nullptr, float last_scale = 0.f) {
     // 512-wide coupling nets inside a guard scope: in_layer + hidden layers as ONE row-resident launch (mlprows.hip); the scratch images
     // of its intermediate activations live in the h[] buffers (same 2 KB per row as a 512-wide fp32 panel)
     // (a workgroup owns 128 rows for the whole chain: with fewer workgroups than ~3/4 of the CUs -- C1's 2 x 1024 points are 16 -- the chain
     // of ONE workgroup is the launch's duration and the per-layer launches on 64 x 64 tiles are faster: 21 vs 38 ms per C1 step)
     if (last_limbs && f.d.H_pad == 512 && gemm_limb_chain_all_ok() && mlp_rows_eligible(m.in_layer, m.mid, act) && mlp_rows_fills_the_chip(w.P_pad)) {
-        launch_mlp_rows(m.in_layer, m.mid, in_segs, rowscal, act, w.h, last_limbs, w.P_pad, w.P, s);
+        launch_mlp_rows(m.in_layer, m.mid, in_segs, rowscal, act, w.h, last_limbs, w.P_pad, w.P, s, last_scale);
         return -1;
     }
-    return run_mlp_hidden_generic(m, in_segs, rowscal, act, w.h, std::max(f.d.H_pad, 32), w.P_pad, s, w.P, last_limbs);
+    return run_mlp_hidden_generic(m, in_segs, rowscal, act, w.h, std::max(f.d.H_pad, 32), w.P_pad, s, w.P, last_limbs, last_scale);
 }
 
 // pre-conditioner: pre-MLP -> LayerNorm -> q -> attention; result in w.a  (models/cif_block.py:14-20 / augmenter.py:15-16)
@@ -673,7 +681,9 @@ static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, c
     const bool chain_aff = c.flow_type == FC_FLOW_AFFINE && !inverse && gemm_limb_chain_all_ok() && b.net.out_layer.W2 != nullptr &&
                            last_hidden.W2 != nullptr && last_hidden.N_pad == b.net.out_layer.K_pad && last_hidden.N_pad % 128 == 0 &&
                            b.net.out_layer.nseg == 1 && !b.net.mid.empty();
-    const int cur = run_mlp_hidden(f, b.net, segs, rowscal, w, c.nonlinearity, s, (chain || chain_aff) ? w.h16 : nullptr);
+    // round 4: the chain's last activation in the one-accumulator form (common.h kOneAccActScale) for the 256 x 256 fused spline kernel (spline_wide.hip)
+    const bool wide = chain && gemm_spline_wide_on() && spline_wide_eligible(b.net.out_layer, c.num_bins_spline) && w.P_pad % 256 == 0;
+    const int cur = run_mlp_hidden(f, b.net, segs, rowscal, w, c.nonlinearity, s, (chain || chain_aff) ? w.h16 : nullptr, wide ? kOneAccActScale : 0.f);
     ASeg a{(chain || chain_aff) ? w.h[0] : w.h[cur], ldh};
     if (c.flow_type == FC_FLOW_AFFINE) {
         GemmEpi e{};
@@ -687,7 +697,7 @@ static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, c
         GemmEpi e{};
         e.xbuf = xc; e.ldx = d.ldx; e.x2_col0 = d.d1_pad; e.d2 = d.d2; e.spline_K = c.num_bins_spline; e.rows_valid = w.P;
         e.ldj_part = w.ldjp; e.ldj_pitch = (size_t)w.P_pad;
-        if (chain) e.A16 = w.h16;
+        if (chain) { e.A16 = w.h16; e.a16_scale = wide ? kOneAccActScale : 0.f; }
         launch_gemm(b.net.out_layer, &a, w.P_pad, e, EPI_SPLINE, s);       // log-dets accumulate in w.ldjp; flow_forward reduces them once
     } else {
         GemmEpi e{};

@@ -712,6 +712,7 @@ void gemm_f32_kernel(const GemmParams p) {
         const float* const gbase = e.gradu ? e.gradu + (size_t)wave_m0 * e.ldgu + wave_n0 : nullptr;
         const int rp16 = (p.N_pad >> 4) * 32;                          // ushorts per row of the limb image
         unsigned short* const hbase = e.C16 ? e.C16 + (size_t)wave_m0 * rp16 + (size_t)(wave_n0 >> 4) * 32 : nullptr;
+        const float c16_s1 = e.c16_scale > 0.f ? e.c16_scale : 1.0f, c16_s2 = e.c16_scale > 0.f ? 1.0f : 2048.0f;
         auto body = [&](auto act_tag, auto fmt_tag) {
             constexpr int ACT = decltype(act_tag)::value;             // 16 + a: no activation, the value is multiplied by act_a'(gradu[row][col]) instead
             constexpr int FMT = decltype(fmt_tag)::value;             // 1: fp32 C, 2: limb image C16, 3: both; 5: fp32 C + the pre-activation value in Cpre
@@ -745,9 +746,11 @@ void gemm_f32_kernel(const GemmParams p) {
                                 // the output ALSO / ONLY as the fp16 limb image a following split-fp16 GEMM copies (its 30 column tiles
                                 // would each re-split the same rows): lanes (c, c+1) swap one half through a DPP quad permute
                                 // ([1,0,3,2]: a VALU move, not the LDS round trip __shfl_xor compiles to) and store one 32-bit word each
-                                omax = fmaxf(omax, fabsf(v));
-                                const _Float16 hb = (_Float16)v;
-                                const _Float16 lb = (_Float16)((v - (float)hb) * 2048.0f);
+                                // (c16_s1, c16_s2) = (1, 2048): x = hi + lo'/2048; (kOneAccActScale, 1): the one-accumulator form hi + lo of x s1 (common.h)
+                                const float vs = v * c16_s1;
+                                omax = fmaxf(omax, fabsf(vs));
+                                const _Float16 hb = (_Float16)vs;
+                                const _Float16 lb = (_Float16)((vs - (float)hb) * c16_s2);
                                 const unsigned hu = __builtin_bit_cast(unsigned short, hb), lu = __builtin_bit_cast(unsigned short, lb);
                                 const unsigned mine = (li & 1) ? lu : hu, give = (li & 1) ? hu : lu;
                                 const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xF, 0xF, true);
@@ -1271,7 +1274,7 @@ size_t gemm_read_stamps(unsigned long long* host, size_t max_n) {
     return n;
 }
 int g_spline_prefetch = 0;   // knob 21: persistent fused spline GEMM (VAR 11): 1 = a tile's k loop starts at a column-tile dependent step and wraps around (measured: no gain, other summation order); 0 = every tile starts at k = 0 (shipped, bit-identical to VAR 7-10)
-int g_gemm_dma = 4;          // knob 13: fused spline GEMM: 4 = persistent transposed LDS-DMA loop, splines evaluated from the accumulator registers (VAR 11, shipped; K = 8 bins), 3 = the same, one tile per workgroup (VAR 10), 2 = LDS-DMA loop on the 128x128 four-wave tile with the LDS parameter tile (VAR 9), 1 = on the 256x128 tile (VAR 8), 0 = register-staged (VAR 7); bit-identical results
+int g_gemm_dma = 5;          // knob 13: fused spline GEMM: 5 = 256 x 256 one-accumulator tile on 16x16x32 MFMAs (spline_wide.hip, shipped round 4; K = 8 bins, limb-chained input; other launches fall to 4), 4 = persistent transposed LDS-DMA loop, splines evaluated from the accumulator registers (VAR 11, shipped; K = 8 bins), 3 = the same, one tile per workgroup (VAR 10), 2 = LDS-DMA loop on the 128x128 four-wave tile with the LDS parameter tile (VAR 9), 1 = on the 256x128 tile (VAR 8), 0 = register-staged (VAR 7); bit-identical results
 int g_spline_ablate = 0;     // knob 14: diagnostics, results invalid (1 = no spline evaluation, 2 = main loop only, 3 = no parameter-tile write, 4 = no x2 store, 5 = stop behind the tile write)
 int g_gemm_small_tiles = 1;  // knob 22: limb-chained Linear launches with at most 256 tiles of 128x128 run on 64x64 tiles
 int g_gemm_dma_linear = 2;   // knob 15: limb-image A in a Linear layer: 2 = LDS-DMA loop on the 128x128 four-wave tile (shipped), 1 = on the 256x128 tile, 0 = register-staged
@@ -1408,12 +1411,13 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
 }
 
 bool gemm_dev_variants() { return kDevVariants; }
+bool gemm_spline_wide_on() { return g_gemm_dma == 5 && g_gemm_variant == 5 && g_gemm_bigtile == 3 && g_fused_spline && g_limb_chain && g_spline_ablate != 3 && g_spline_ablate != 4 && g_spline_ablate != 5; }
 
 void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const GemmEpi& e_in, int epi_kind, hipStream_t s) {
     if (rows_alloc % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "launch_gemm: rows must be padded to ROW_PAD");
     const int v_bigtile = kDevVariants ? g_gemm_bigtile : 3;
     const int v_dma_linear = kDevVariants ? g_gemm_dma_linear : 2;
-    const int v_dma = kDevVariants ? g_gemm_dma : (g_gemm_dma == 2 ? 2 : 4);      // (2: the LDS-tile epilogue on the four-wave DMA tile -- in every build: it serves 4 and 16 bins)
+    const int v_dma = kDevVariants ? g_gemm_dma : (g_gemm_dma == 2 ? 2 : 4);      // (5, the shipped wide kernel, takes one-accumulator images only: spline_wide.hip)      // (2: the LDS-tile epilogue on the four-wave DMA tile -- in every build: it serves 4 and 16 bins)
     const int v_variant = kDevVariants ? g_gemm_variant : (g_gemm_variant < 2 ? 2 : g_gemm_variant);
     (void)v_bigtile; (void)v_dma_linear; (void)v_dma;
     if (L.K_pad % 32 != 0 || L.N_pad % 32 != 0 || L.nseg < 1 || L.nseg > 3) throw Error(FC_ERR_INVALID, "launch_gemm: bad packing");
@@ -1446,6 +1450,7 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         if (e.Cpre && (!e.C || e.C16)) throw Error(FC_ERR_INVALID, "launch_gemm: a pre-activation output goes with an fp32 C and no limb image");
         if (e.C16 && !(f16 && v_bigtile == 3 && L.N_pad > 64 && L.N_pad % 16 == 0))
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: limb-image output exists on the eight-wave split-fp16 tile only");
+        if (e.a16_scale != 0.f) throw Error(FC_ERR_INVALID, "launch_gemm: a one-accumulator activation image is an input of the fused spline layer only");
         if (e.A16) {
             p.e.inverse = g_spline_ablate;
             // A arrives as the limb image of the producing layer (limb-chained MLP): the copy-only main loops
@@ -1507,10 +1512,15 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         if ((K != 4 && K != 8 && K != 16) || L.N_pad != spline_ncols(e.d2, K) || !e.xbuf || !e.ldj_part || e.ldj_pitch < (size_t)rows_alloc)
             throw Error(FC_ERR_INVALID, "launch_gemm: bad fused-spline arguments (layout of spline.h, per-tile log-det buffer)");
         p.nbm = rows_alloc / 128;
+        if (e.a16_scale != 0.f && !(f16 && e.A16 && v_bigtile == 3)) throw Error(FC_ERR_INVALID, "launch_gemm: a one-accumulator activation image outside the split-fp16 guard scope");
         if (f16 && e.A16 && v_bigtile == 3) {
             if (L.nseg != 1) throw Error(FC_ERR_INVALID, "launch_gemm: a limb-image A operand must be the only segment");
             if (L.n_alloc < round_up(L.N_pad, 128)) throw Error(FC_ERR_INVALID, "launch_gemm: fused spline layer not padded to the 128-column tile grid");
-            if (v_dma == 4 && K == 8 && L.bias) launch_cfg<128, 128, 4, 1, EPI_SPLINE, 11>(p, s);
+            if (e.a16_scale != 0.f) {                                   // the one-accumulator image: only spline_wide.hip reads it
+                if (!(g_gemm_dma == 5 && spline_wide_eligible(L, K))) throw Error(FC_ERR_INVALID, "launch_gemm: a one-accumulator activation image needs the wide fused spline kernel (knob 13 = 5)");
+                launch_spline_wide(L, p.e, rows_alloc, s);
+            }
+            else if (v_dma >= 4 && K == 8 && L.bias) launch_cfg<128, 128, 4, 1, EPI_SPLINE, 11>(p, s);
             FC_DEV(else if (v_dma == 3 && K == 8 && L.bias) launch_cfg<128, 128, 4, 1, EPI_SPLINE, 10>(p, s);)
             else if (v_dma >= 2) launch_cfg<128, 128, 2, 2, EPI_SPLINE, 9>(p, s);      // (4 and 16 bins: the LDS-tile epilogue on the four-wave DMA tile)
             FC_DEV(else if (v_dma == 1 && rows_alloc % 256 == 0) { p.nbm = rows_alloc / 256; launch_cfg<256, 128, 4, 2, EPI_SPLINE, 8>(p, s); }

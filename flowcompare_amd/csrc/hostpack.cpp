@@ -388,7 +388,7 @@ void pack_mlp_mid(DeviceArena& arena, const WeightTable& wt, const std::string& 
     if (w_out.shape.size() != 2 || w_out.shape[1] != out.sizes.back()) throw Error(FC_ERR_SHAPE, prefix + ".out_layer.weight: input width mismatch");
 }
 int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float* rowscal, int act, float* const h[3], int ldh, int rows,
-                           hipStream_t s, int rows_valid, unsigned short* last_limbs) {
+                           hipStream_t s, int rows_valid, unsigned short* last_limbs, float last_scale) {
     // Full limb chain (with `last_limbs`, inside a guard scope, every layer with an fp16 image and 128-multiple widths): EVERY hidden
     // activation exists only as the fp16 limb image its producer's epilogue writes (same 4 bytes per element as fp32, in the h[] buffers);
     // the consumers copy it (A16: no conversion in the main loop, LDS-DMA) and the odd layers read their residual from the image too.
@@ -397,7 +397,7 @@ int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float*
     for (const PackedLinear& L : m.mid) { all = all && L.W2 && L.nseg == 1 && L.N_pad % 128 == 0 && L.K_pad == prev_n && L.N_pad <= ldh; prev_n = L.N_pad; }
     GemmEpi e{};
     e.act = act; e.C = h[0]; e.ldc = ldh; e.rowscal = rowscal; e.rows_valid = rows_valid;
-    if (last_limbs && m.mid.empty()) { e.C = nullptr; e.C16 = last_limbs; }
+    if (last_limbs && m.mid.empty()) { e.C = nullptr; e.C16 = last_limbs; e.c16_scale = last_scale; }
     else if (all) { e.C = nullptr; e.C16 = reinterpret_cast<unsigned short*>(h[0]); }
     launch_gemm(m.in_layer, in_segs, rows, e, EPI_LINEAR, s);
     int cur = 0, keep = -1;
@@ -413,9 +413,10 @@ int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float*
             if (i % 2 == 1) { g.residual16 = reinterpret_cast<const unsigned short*>(h[keep]); g.ldr16 = m.mid[i].N_pad; }
             g.C = nullptr;
             g.C16 = last ? last_limbs : reinterpret_cast<unsigned short*>(h[nxt]);
+            if (last) g.c16_scale = last_scale;
         } else {
             if (i % 2 == 1) { g.residual = h[keep]; g.ldr = ldh; }
-            if (last_limbs && last) { g.C = nullptr; g.C16 = last_limbs; }
+            if (last_limbs && last) { g.C = nullptr; g.C16 = last_limbs; g.c16_scale = last_scale; }
         }
         ASeg a{h[cur], ldh};
         launch_gemm(m.mid[i], &a, rows, g, EPI_LINEAR, s);

@@ -25,6 +25,8 @@ struct MlpRowsParams {
     unsigned short* hbuf[3];                        // three rotating fragment-major activation images [rows / 32][32][2][64][8] fp16
     unsigned short* out16;                          // last layer's output: row-major limb image [rows][32][hi 16 | lo' 16] (GemmEpi::A16)
     int* ovf;                                       // split-fp16 range flag (common.h Fp16Guard)
+    float out_s1, out_s2;                           // the last layer's limb split: hi = rn16(v s1), lo = rn16((v s1 - hi) s2): (1, 2048) or the one-accumulator form (kOneAccActScale, 1)
+    float range_limit;                              // |activation| at or beyond this raises the flag (65504 / out_s1)
     int rows_valid;
     unsigned long long* stamps;                     // diagnostic knob 20 = 4 (in-kernel phase stamps), else null
 };

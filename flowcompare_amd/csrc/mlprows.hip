@@ -217,6 +217,7 @@ void mlp_rows_kernel(const MlpRowsParams p) {
         static_assert(!HAS_RES || NSB == 4, "only the 512 -> 512 hidden layers carry a residual");
         const MlpRowsLayer& L = p.L[l];
         const bool last = l + 1 == p.nlayers;
+        const float sp1 = last ? p.out_s1 : 1.0f, sp2 = last ? p.out_s2 : 2048.0f;      // the output's limb split (the last layer may write the one-accumulator form)
         const char* resbase = HAS_RES ? reinterpret_cast<const char*>(p.hbuf[L.res]) + band * band_bytes + lane * 16 : nullptr;
         // output: fragment-major scratch image (k-step stride 2 KiB, limb stride 1 KiB) or, for the last layer, the row-major limb image
         // (k-step stride 64 B, limb stride 32 B)
@@ -311,9 +312,9 @@ void mlp_rows_kernel(const MlpRowsParams p) {
                     ev[Q][t] = r;
                 } else if constexpr (hs == 8) {
                     if (tt == 1) {
-                        // the pair's limb words in 5 instructions (activations.h limb_split2)
+                        // the pair's limb words in 6 instructions (activations.h limb_split2s: run-time scales, (1, 2048) = limb_split2's bits)
                         unsigned wh2, wl2;
-                        limb_split2(ev[Q][2 * pr], ev[Q][2 * pr + 1], wh2, wl2);
+                        limb_split2s(ev[Q][2 * pr], ev[Q][2 * pr + 1], sp1, sp2, wh2, wl2);
                         MR_PIN(wh2); MR_PIN(wl2);
                         outq[g][0][pr] = wh2;
                         outq[g][1][pr] = wl2;
@@ -498,7 +499,7 @@ void mlp_rows_kernel(const MlpRowsParams p) {
         else run_layer(std::integral_constant<int, MR_HID / 16>{}, std::false_type{}, std::false_type{}, l);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // drain the stream's tail re-loads before the LDS is released
-    if (!(omax < 65504.0f) && p.ovf) atomicOr(p.ovf, 1);                // (also on a NaN)
+    if (!(omax < p.range_limit) && p.ovf) atomicOr(p.ovf, 1);           // (also on a NaN; 65504 / the last layer's pre-scale: conservative for the layers before it)
 }
 
 // ---------------------------------------------------------------- fragment-major weight image
@@ -584,7 +585,7 @@ bool mlp_rows_eligible(const PackedLinear& in, const std::vector<PackedLinear>& 
 }
 
 void launch_mlp_rows(const PackedLinear& in, const std::vector<PackedLinear>& mid, const ASeg* segs, const float* rowscal, int act,
-                     float* const h[3], unsigned short* out16, int rows_alloc, int rows_valid, hipStream_t s) {
+                     float* const h[3], unsigned short* out16, int rows_alloc, int rows_valid, hipStream_t s, float out16_scale) {
     if (!mlp_rows_eligible(in, mid, act)) throw Error(FC_ERR_UNSUPPORTED, "launch_mlp_rows: shapes outside the row-resident chain");
     if (rows_alloc % 128 != 0 || !out16) throw Error(FC_ERR_INVALID, "launch_mlp_rows: rows must be padded to 128 and a limb-image output given");
     int* flag = gemm_fp16_flag();
@@ -601,6 +602,9 @@ void launch_mlp_rows(const PackedLinear& in, const std::vector<PackedLinear>& mi
     p.nlayers = 1 + (int)mid.size();
     p.ovf = flag;
     p.out16 = out16;
+    p.out_s1 = out16_scale > 0.f ? out16_scale : 1.0f;
+    p.out_s2 = out16_scale > 0.f ? 1.0f : 2048.0f;
+    p.range_limit = 65504.0f / p.out_s1;
     p.rows_valid = rows_valid > 0 ? rows_valid : rows_alloc;
     for (int i = 0; i < 3; ++i) p.hbuf[i] = reinterpret_cast<unsigned short*>(h[i]);
     const int ks0 = mlp_rows_ks_pad(in.K_pad);

@@ -24,7 +24,7 @@ extern "C" {
 
 /* tuning knobs for profiles/kernel_bench.py (not part of the stable ABI surface in fcflow.h on purpose) */
 int fc_debug_set(int32_t key, int32_t value) {
-    if (!fc::kDevVariants && ((key == 0 && (value == 0 || value == 1)) || (key == 3 && value != 3) || (key == 8 && value == 1) || (key == 13 && value != 4 && value != 2) ||
+    if (!fc::kDevVariants && ((key == 0 && (value == 0 || value == 1)) || (key == 3 && value != 3) || (key == 8 && value == 1) || (key == 13 && value != 5 && value != 4 && value != 2) ||
                               (key == 15 && value != 2) || (key == 17 && value != 0)))
         return FC_ERR_UNSUPPORTED;       /* a developer variant: compiled only with -DFC_DEV_VARIANTS (python -m flowcompare_amd.build --dev) */
     if (key == 0) fc::g_gemm_variant = value;

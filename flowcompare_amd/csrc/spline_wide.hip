@@ -1,0 +1,440 @@
+// The fused spline parameter layer, round 4: a PERSISTENT 256 x 256 workgroup tile on v_mfma_f32_16x16x32_f16 with ONE accumulator per output.
+//
+//   params[rows, 3750] = h[rows, 512] W^T + b ;  y2, log-det = RQ-spline(x2; params)      (models/spline_coupling.py:187-210, models/nets.py:19-30)
+//
+// Why another kernel (profiles/micro/wide_gemm_probe.hip measured the structure first): the shipped VAR 11 loop
+// (gemm.hip: 128 x 128 tile, 32x32x16 MFMAs, main + cross-product accumulator sets) sat at 48 % matrix-pipe busy at 1.94 GHz for two rounds
+// whatever the loop order.  Three things change here, each measured in the probe:
+//   * ONE accumulator set.  The low limb is stored UNSCALED, lo = rn16(x - hi) (fp16 subnormals are honoured by the MFMA at full rate), so the
+//     three limb products hi.hi + lo.hi + hi.lo land at their true scale in one fp32 accumulator.  Operands are pre-scaled by exact powers of
+//     two so that lo stays a normal fp16 number for every value that matters: activations by kOneAccActScale (their producer's epilogue
+//     writes the image that way), weights per layer so that max |w| lands in [2^14, 2^15) (spline_wide_attach); the product is scaled back
+//     inside the spline's own first fma.  Error against fp64 at K = 512: 6.9e-8 mean / 7.1e-7 max on unit-scale outputs, below the fp32 fmaf
+//     chain (1.05e-7 / 1.24e-6) at all three weight scales of the probe (tests/test_gpu_ops.py::test_one_accumulator_limb_form...).
+//   * Half the accumulator registers pay for a 64-point x 128-parameter WAVE tile and a 256 x 256 workgroup tile: half the LDS-DMA bytes and
+//     0.6 of the LDS fragment reads per MFMA of VAR 11.
+//   * The 16x16x32 MFMA shape: the chip holds a higher clock on it (MI355X_MICROARCH.md, DVFS give-back item 7): main loop alone 0.50 ms
+//     against 0.60-0.62 ms for the same tile on 32x32x16, same box.
+// Structure (the guide's 8-phase GEMM template, cdna_hip_programming.md section 5): eight waves = 4 point blocks of 64 x 2 parameter tiles of
+// 128; waves w and w + 4 share a SIMD and belong to different GROUPS; a k32 step is four phases {LOAD: fragment reads + DMA issue | barrier |
+// 24 MFMAs | barrier} and group 1 runs ONE barrier behind group 0, so that on every SIMD one wave multiplies while its partner loads.
+// Two 64 KB LDS stages (k32 of 256 point rows + 256 weight rows), LDS-DMA pieces of 8 rows x 128 B with the XOR swizzle on the source
+// address, one continuous stream across the workgroup's tiles, bias (pre-scaled) and the x2 / log-det operands of the next tile fetched
+// during the last k step.
+// Epilogue in registers: with the weights as the MFMA's A operand a lane of row kq = lane >> 4 holds, for the point lane & 15 of each of
+// the wave's four 16-point blocks, the 32 parameters "slot s" = 4 (16-parameter block) + register.  The layer's columns are packed so that
+// slots 0..24 of row kq are ALL 25 parameters of transformed dim kq of the tile and slots 25..31 a part of dim 4 (7 + 6 + 6 + 6): four
+// whole-wave evaluations (every lane busy: 16 points x 4 dims) and a fifth in which row kq takes dim 4 of point block kq after a 4 x 4
+// transpose of those seven registers across the rows (v_permlane16_swap + v_permlane32_swap, one swap per register).  64 points x 5 dims =
+// 5 full wave evaluations (VAR 11: 6 for the same points, one half empty).
+#include "common.h"
+#include "spline.h"
+#include <cstdio>
+
+namespace fc {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct SplineWideParams {
+    const unsigned short* A16;   // [rows][KT][64] fp16: the activation image, one-accumulator form (pre-scaled by kOneAccActScale, lo unscaled)
+    const unsigned short* W1;    // [nbn * 256][KT][64] fp16: the weight image in this kernel's column order, pre-scaled by 2^w1_exp
+    const float* bias1;          // [nbn * 256] bias in the same order, times kOneAccActScale * 2^w1_exp
+    float* xbuf; int ldx; int x2_col0; int d2; int rows_valid;
+    float* ldj_part; size_t ldj_pitch;
+    int KT;                      // k32 steps (even)
+    int nbm, nbn;                // 256-row tiles, 256-column tiles (= pairs of 128-column spline tiles)
+    int ntile128;                // 128-column spline tiles that exist (the last pair may be half empty)
+    int col_group;
+    float out_scale;             // 1 / (kOneAccActScale * 2^w1_exp)
+    int ablate;                  // diagnostic knob 14: 1 no spline evaluation, 2 main loop only (results invalid)
+};
+
+// column of the kernel's tile order: row kq = (c >> 2) & 3 of 16-parameter block jb = c >> 4, register r = c & 3 -> slot s = 4 jb + r
+//   s < 25: parameter s of the tile's dim kq;  s >= 25: parameter base(kq) + s - 25 of dim 4 (kq = 0: 0..6, 1: 7..12, 2: 13..18, 3: 19..24)
+// returns the column of the SAME tile in spline.h's order (what PackedLinear.W holds), or -1 for the three unused slots
+__host__ __device__ inline int spline_wide_src_col(int c) {
+    const int jb = c >> 4, kq = (c >> 2) & 3, r = c & 3, s = 4 * jb + r;
+    if (s < 25) return spline_col(kq, s, 8);
+    const int base = kq == 0 ? 0 : 1 + 6 * kq, cnt = kq == 0 ? 7 : 6, i = s - 25;
+    return i < cnt ? spline_col(4, base + i, 8) : -1;
+}
+
+// ---------------------------------------------------------------- weight image + bias in the kernel's order (fc_flow_create)
+__global__ __launch_bounds__(256) void spline_wide_image_kernel(const float* __restrict__ W, const float* __restrict__ bias, int n_src, int K_pad, float wscale,
+                                                                float bscale, unsigned short* __restrict__ W1, float* __restrict__ bias1, size_t n) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const size_t row = t / K_pad;
+    const int k = (int)(t - row * K_pad);
+    const int tile = (int)(row >> 7), c = (int)(row & 127);
+    const int sc = spline_wide_src_col(c);
+    const int srow = tile * 128 + sc;
+    const bool live = sc >= 0 && srow < n_src;
+    const float x = live ? W[(size_t)srow * K_pad + k] * wscale : 0.f;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    const size_t blk = row * (K_pad / 16) + k / 16;
+    W1[blk * 32 + (k & 15)] = __builtin_bit_cast(unsigned short, h);
+    W1[blk * 32 + 16 + (k & 15)] = __builtin_bit_cast(unsigned short, l);
+    if (k == 0) bias1[row] = live ? bias[srow] * bscale : 0.f;
+}
+
+int g_spline_wide_dma = 0;   // developer knob 27: DMA pieces per phase, 0 = {1,3,3,1} / {2,3,3,0} (shipped)
+
+// rows of 16 lanes (a0,a1,a2,a3 | b0,b1,b2,b3):  swap32 -> a = (a0,a1,b0,b1), b = (a2,a3,b2,b3) ;  swap16 -> a = (a0,b0,a2,b2), b = (a1,b1,a3,b3)
+__device__ __forceinline__ void sw_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void sw_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+// sum over the four rows of 16 lanes, result in every row (fixed order: (r0 + r1) + (r2 + r3))
+__device__ __forceinline__ float sw_row_sum(float v) {
+    float a = v, b = v;
+    sw_swap16(a, b);
+    float c = a + b, d = c;
+    sw_swap32(c, d);
+    return c + d;
+}
+
+// rq_spline_fwd_regs (spline.h) on parameters that arrive SCALED: logical parameter i = u(i) * os with os an exact power of two.  The
+// scale rides inside the softmax's existing fma (fma(u, L2E os, -max u L2E os) is bit for bit fma(u os, L2E, -max(u os) L2E)), the two
+// derivative logits are scaled after their selection: same operations and roundings as the unscaled routine on u os.
+template <int K, class U>
+__device__ __forceinline__ void rq_spline_fwd_regs_scaled(float x, const U& u, float os, float& y, float& lad) {
+    constexpr float B = 3.0f, MINW = 1e-3f, MINH = 1e-3f, MIND = 1e-3f, L2E = 1.4426950408889634f;
+    const bool inside = x >= -B && x <= B;
+    const float l2s = L2E * os;
+    float ew[K], eh[K], mw = u(0), mh = u(K);
+#pragma unroll
+    for (int i = 0; i < K; ++i) { ew[i] = u(i); eh[i] = u(K + i); mw = fmaxf(mw, ew[i]); mh = fmaxf(mh, eh[i]); }
+    float sw = 0.f, sh = 0.f;
+    const float ow = -mw * l2s, oh = -mh * l2s;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        ew[i] = __builtin_amdgcn_exp2f(fmaf(ew[i], l2s, ow)); sw += ew[i];
+        eh[i] = __builtin_amdgcn_exp2f(fmaf(eh[i], l2s, oh)); sh += eh[i];
+    }
+    const float fw = (1.0f - MINW * K) * __builtin_amdgcn_rcpf(sw), fh = (1.0f - MINH * K) * __builtin_amdgcn_rcpf(sh);
+    float c = 0.f, in_cw = -B, hi = INFINITY;
+    float ud0r = 0.f, ud1r = u(2 * K);
+    int bin = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        c += fmaf(fw, ew[i], MINW);
+        const float knot = i == K - 1 ? B : fmaf(2.0f * B, c, -B);
+        const bool ge = x >= (i == K - 1 ? knot + 1e-6f : knot);
+        bin += ge ? 1 : 0;
+        in_cw = ge ? knot : in_cw;
+        hi = ge ? hi : fminf(hi, knot);
+        ud0r = ge ? u(2 * K + i) : ud0r;
+        ud1r = ge ? u(2 * K + i + 1) : ud1r;
+    }
+    const float in_w = hi - in_cw;
+    float ch = 0.f, in_ch = -B, ch_hi = B;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        ch += fmaf(fh, eh[i], MINH);
+        const float knot = i == K - 1 ? B : fmaf(2.0f * B, ch, -B);
+        in_ch = (i + 1 == bin) ? knot : in_ch;
+        ch_hi = (i == bin) ? knot : ch_hi;
+    }
+    const float in_h = ch_hi - in_ch;
+    const float ud0 = bin == 0 ? -1e-3f : ud0r * os, ud1 = ud1r * os;      // bin 0: left pad log(exp(1 - min_derivative - 1))
+    const float d0 = MIND + (ud0 > 20.f ? ud0 : fast_log(1.0f + fast_exp(ud0)));
+    const float d1 = MIND + (ud1 > 20.f ? ud1 : fast_log(1.0f + fast_exp(ud1)));
+    const float rw = __builtin_amdgcn_rcpf(in_w);
+    const float delta = in_h * rw;
+    const float th = (x - in_cw) * rw;
+    const float tt = th * (1.0f - th);
+    const float num = in_h * (delta * th * th + d0 * tt);
+    const float den = delta + (d0 + d1 - 2.0f * delta) * tt;
+    const float yy = in_ch + fast_div(num, den);
+    const float omt = 1.0f - th;
+    const float dnum = delta * delta * (d1 * th * th + 2.0f * delta * tt + d0 * omt * omt);
+    const float ll = fast_log(dnum) - 2.0f * fast_log(den);
+    y = inside ? yy : x;
+    lad = inside ? ll : 0.f;
+}
+
+constexpr int SW_LDS = 4 * 32768 + 2 * 1024;      // two stages of (256 point rows + 256 weight rows) x 128 B, two bias buffers of 256 floats
+
+// DMA pieces per LOAD segment of a k step, for the group that fetches the points (waves 0-3: P*) and the weights (waves 4-7: Q*); the
+// lagging group must not issue in its last segment (it waits for its pieces there)
+template <int P0, int P1, int P2, int P3, int Q0, int Q1, int Q2, int Q3>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
+void spline_wide_kernel(const SplineWideParams p) {
+    static_assert(P0 + P1 + P2 + P3 == 8 && Q0 + Q1 + Q2 == 8 && Q3 == 0, "eight pieces per wave and k step");
+    extern __shared__ char smc[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef const __attribute__((address_space(1))) char glb_char;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, pw = wave & 3;
+    const int KT = p.KT;
+    const unsigned rowbytes = (unsigned)KT * 128u;
+    const int ntiles = p.nbm * p.nbn, G = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= ntiles) return;
+    float* biasbuf = reinterpret_cast<float*>(smc + 4 * 32768);          // [2][256]
+
+    auto tile_of = [&](int b, int& bm, int& bn) {                       // XCD-aware order (gemm.hip): blocks b, b + 8, ... share an XCD
+        const int xcd = b & 7, loc = b >> 3;
+        if (p.col_group > 0) {
+            const int rows_x = p.nbm >> 3, Gc = p.col_group;
+            const int g = loc / (rows_x * Gc);
+            const int rem = loc - g * rows_x * Gc;
+            const int w = p.nbn - g * Gc < Gc ? p.nbn - g * Gc : Gc;
+            const int r = rem / w;
+            bm = xcd * rows_x + r;
+            bn = g * Gc + (rem - r * w);
+        } else {
+            const int q = ntiles >> 3, r = ntiles & 7;
+            const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+            bm = L / p.nbn;
+            bn = L - bm * p.nbn;
+        }
+    };
+    // LDS: [stage 0 points 32 KB | stage 1 points | stage 0 weights | stage 1 weights]; a row = 128 B = one k32 step of one point / weight row
+    // = 8 chunks of 16 B, logical chunk c = 4 (k16 block) + 2 limb + (k half) at physical chunk c ^ ((row >> 1) & 7).
+    // DMA piece i of this wave: operand rows (wave & 3) * 64 + 8 i + (lane >> 3); the swizzle term depends on the parity of i only.
+    unsigned poff[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int r = pw * 64 + par * 8 + (lane >> 3);
+        const int cl = (lane & 7) ^ ((r >> 1) & 7);
+        poff[par] = (unsigned)r * rowbytes + cl * 16;
+    }
+    auto src_of = [&](int bm, int bn) -> const char* {
+        return grp == 0 ? reinterpret_cast<const char*>(p.A16) + (size_t)bm * 256 * rowbytes : reinterpret_cast<const char*>(p.W1) + (size_t)bn * 256 * rowbytes;
+    };
+    const int dst0 = grp * 65536 + pw * 8192;
+#define SW_DMA(SRC_, ST_, I0_, N_)                                                                                                      \
+    {                                                                                                                                     \
+        _Pragma("unroll") for (int i_ = (I0_); i_ < (I0_) + (N_); ++i_)                                                                 \
+            __builtin_amdgcn_global_load_lds((glb_char*)((SRC_) + (size_t)(i_ >> 1) * 16 * rowbytes + poff[i_ & 1]),                      \
+                                             (lds_char*)(smc + dst0 + (ST_) * 32768 + i_ * 1024), 16, 0, 0);                            \
+    }
+    auto bias_dma = [&](int bn, int par) {                              // 256 floats: waves 0-3, 4 bytes per lane
+        if (grp == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) float*)(p.bias1 + bn * 256 + pw * 64 + lane),
+                                             (__attribute__((address_space(3))) float*)(biasbuf + par * 256 + pw * 64), 4, 0, 0);
+    };
+    // a k32 step is ONE k extent of the 16x16x32 MFMA: lane (l15, kq) supplies row l15 of a 16-row block, k quarter kq = chunks 0, 1, 4, 5 of
+    // the hi limb / 2, 3, 6, 7 of the lo limb
+    const int xsw = (l15 >> 1) & 7;
+    int abase[2], bbase[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = (((kq >> 1) * 4 + q * 2 + (kq & 1)) ^ xsw) * 16;
+        abase[q] = (pw * 64 + l15) * 128 + c;
+        bbase[q] = 65536 + (grp * 128 + l15) * 128 + c;
+    }
+    // this lane's share of a tile's x2 operands: dim kq of point (ib, l15) for ib = 0..3, dim 4 of point (kq, l15), and that point's log-det slot
+    auto load_x = [&](int bm, int bn, float (&x)[5], float& ldj) {
+        const int t128 = 2 * bn + grp, dim0 = t128 * 5;
+        const int row0 = bm * 256 + pw * 64 + l15;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const int row = row0 + 16 * ib;
+            x[ib] = row < p.rows_valid && dim0 + kq < p.d2 ? p.xbuf[(size_t)row * p.ldx + p.x2_col0 + dim0 + kq] : 0.f;
+        }
+        const int rowq = row0 + 16 * kq;
+        x[4] = rowq < p.rows_valid && dim0 + 4 < p.d2 ? p.xbuf[(size_t)rowq * p.ldx + p.x2_col0 + dim0 + 4] : 0.f;
+        ldj = t128 < p.ntile128 ? p.ldj_part[(size_t)t128 * p.ldj_pitch + rowq] : 0.f;
+    };
+
+    int bm, bn;
+    tile_of(t, bm, bn);
+    const char* src = src_of(bm, bn);
+    SW_DMA(src, 0, 0, 8)
+    bias_dma(bn, 0);
+    float spl_x[5], spl_ldj;
+    load_x(bm, bn, spl_x, spl_ldj);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();                         // the second group runs one segment behind the first
+
+    floatx4 acc[4][8];
+    int par = 0;
+    for (;;) {
+        const int tn = t + G;
+        const bool has_next = tn < ntiles;
+        int nbm = bm, nbn = bn;
+        if (has_next) tile_of(tn, nbm, nbn);
+        const char* nsrc = src_of(nbm, nbn);
+        float nx[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, nldj = 0.f;
+        {
+            // accumulators start from the (pre-scaled) bias: register r of block jb is tile column 16 jb + 4 kq + r for every point block
+            const float* bb = biasbuf + par * 256 + grp * 128 + 4 * kq;
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bb + jb * 16);
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) { acc[ib][jb][0] = b4.x; acc[ib][jb][1] = b4.y; acc[ib][jb][2] = b4.z; acc[ib][jb][3] = b4.w; }
+            }
+        }
+#define SW_PHASE(ST_, F_, NP_, NQ_, I0P_, I0Q_, LAST_)                                                                                   \
+        {                                                                                                                                 \
+            if ((F_) == 0) {                                                                                                              \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                            \
+                    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                        \
+                        xf[i][q] = *reinterpret_cast<const f16x8*>(smc + abase[q] + (ST_) * 32768 + i * 2048);                            \
+            }                                                                                                                             \
+            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                             \
+                _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                            \
+                    wf[jj][q] = *reinterpret_cast<const f16x8*>(smc + bbase[q] + (ST_) * 32768 + (2 * (F_) + jj) * 2048);                 \
+            if (grp == 0) { if ((NP_) > 0) SW_DMA(dsrc, (ST_) ^ 1, I0P_, NP_) }                                                          \
+            else { if ((NQ_) > 0) SW_DMA(dsrc, (ST_) ^ 1, I0Q_, NQ_) }                                                                   \
+            if ((LAST_) && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            __builtin_amdgcn_s_barrier();                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            __builtin_amdgcn_s_setprio(1);                                                                                                \
+            _Pragma("unroll") for (int pr = 0; pr < 3; ++pr)                                                                             \
+                _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                         \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                        \
+                        acc[i][2 * (F_) + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jj][pr == 1 ? 1 : 0], xf[i][pr == 2 ? 1 : 0],  \
+                                                                                       acc[i][2 * (F_) + jj], 0, 0, 0);                   \
+            __builtin_amdgcn_s_setprio(0);                                                                                                \
+            if ((LAST_) && grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            __builtin_amdgcn_s_barrier();                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        }
+#define SW_STEP(ST_)                                                                                                                      \
+        {                                                                                                                                 \
+            SW_PHASE(ST_, 0, P0, Q0, 0, 0, 0)                                                                                             \
+            SW_PHASE(ST_, 1, P1, Q1, P0, Q0, 0)                                                                                           \
+            SW_PHASE(ST_, 2, P2, Q2, P0 + P1, Q0 + Q1, 0)                                                                                 \
+            SW_PHASE(ST_, 3, P3, Q3, P0 + P1 + P2, Q0 + Q1 + Q2, 1)                                                                       \
+        }
+        f16x8 xf[4][2], wf[2][2];
+        for (int kt = 0; kt < KT; kt += 2) {
+            const char* dsrc = src + (size_t)(kt + 1) * 128;
+            SW_STEP(0)
+            const bool lastk = kt + 2 >= KT;
+            dsrc = lastk ? nsrc : src + (size_t)(kt + 2) * 128;
+            if (lastk && has_next) {                                    // the stream runs on into the next tile: its bias and x2 / log-det operands too
+                bias_dma(nbn, par ^ 1);
+                load_x(nbm, nbn, nx, nldj);
+            }
+            SW_STEP(1)
+        }
+        // ---------------------------------------------------------------- epilogue in registers
+        if (p.ablate != 2) {
+            const float os = p.out_scale;
+            const int t128 = 2 * bn + grp, dim0 = t128 * 5;
+            const int row0 = bm * 256 + pw * 64 + l15, rowq = row0 + 16 * kq;
+            // slots 25..31 (registers 1..3 of block 6, 0..3 of block 7): the parts of dim 4 -> row d gets the parts of point block d
+#pragma unroll
+            for (int s = 25; s < 32; ++s) {
+                float x0 = acc[0][s >> 2][s & 3], x1 = acc[1][s >> 2][s & 3], x2 = acc[2][s >> 2][s & 3], x3 = acc[3][s >> 2][s & 3];
+                sw_swap16(x0, x1);
+                sw_swap16(x2, x3);
+                sw_swap32(x0, x2);
+                sw_swap32(x1, x3);
+                acc[0][s >> 2][s & 3] = x0; acc[1][s >> 2][s & 3] = x1; acc[2][s >> 2][s & 3] = x2; acc[3][s >> 2][s & 3] = x3;
+            }
+            float yv[5], lv[5];
+            if (p.ablate == 1) {
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) { yv[ib] = spl_x[ib] + acc[ib][0][0] * os; lv[ib] = acc[ib][0][1] * os; }
+                yv[4] = spl_x[4] + acc[0][6][1] * os; lv[4] = acc[1][6][1] * os;
+            } else {
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+                    rq_spline_fwd_regs_scaled<8>(spl_x[ib], [&](int q) { return acc[ib][q >> 2][q & 3]; }, os, yv[ib], lv[ib]);
+                // dim 4: parameters 0..6 from (transposed) block 0, 7..12 from block 1, 13..18 from block 2, 19..24 from block 3, slots 25 + i
+                rq_spline_fwd_regs_scaled<8>(spl_x[4], [&](int q) {
+                    const int part = q < 7 ? 0 : (q - 1) / 6, s = 25 + (q < 7 ? q : (q - 1) % 6);
+                    return acc[part][s >> 2][s & 3];
+                }, os, yv[4], lv[4]);
+            }
+            const bool dk = dim0 + kq < p.d2, d4 = dim0 + 4 < p.d2;
+            float tot = 0.f;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const bool v = dk && row0 + 16 * ib < p.rows_valid;
+                const float s4 = sw_row_sum(v ? lv[ib] : 0.f);             // dims 0..3 of point (ib, l15), in every row
+                tot = kq == ib ? s4 : tot;
+                if (v) p.xbuf[(size_t)(row0 + 16 * ib) * p.ldx + p.x2_col0 + dim0 + kq] = yv[ib];
+            }
+            const bool vq = rowq < p.rows_valid;
+            if (vq && d4) { p.xbuf[(size_t)rowq * p.ldx + p.x2_col0 + dim0 + 4] = yv[4]; tot += lv[4]; }
+            if (t128 < p.ntile128) p.ldj_part[(size_t)t128 * p.ldj_pitch + rowq] = spl_ldj + tot;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+        }
+        if (!has_next) break;
+        t = tn; bm = nbm; bn = nbn; src = nsrc; par ^= 1;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) spl_x[i] = nx[i];
+        spl_ldj = nldj;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef SW_DMA
+#undef SW_PHASE
+#undef SW_STEP
+}
+
+// ---------------------------------------------------------------- host side
+bool spline_wide_eligible(const PackedLinear& L, int K_bins) {
+    return K_bins == 8 && L.W1 != nullptr && L.bias1 != nullptr && L.nseg == 1 && L.K_pad % 64 == 0 && L.N_pad % 128 == 0;
+}
+
+// Attaches the kernel's weight image and bias to the packed spline parameter layer (K = 8 bins; W / bias hold spline.h's column order).
+// wmax = max |w| over the layer (host side, from the checkpoint tensor).
+void spline_wide_attach(DeviceArena& arena, PackedLinear& L, float wmax, hipStream_t s) {
+    if (!L.W || !L.bias || !L.W2 || L.nseg != 1 || L.K_pad % 64 != 0 || L.N_pad % 128 != 0 || L.n_alloc < L.N_pad) return;
+    if (!(wmax < 65504.0f)) return;
+    int e = 0;
+    if (wmax > 0.f) {
+        while (ldexpf(wmax, e) >= 32768.0f) --e;
+        while (ldexpf(wmax, e) < 16384.0f && e < 100) ++e;
+    }
+    const int rows = round_up(L.N_pad, 256);
+    const size_t n = (size_t)rows * L.K_pad;
+    L.W1 = (unsigned short*)arena.alloc_bytes(n * 2 * sizeof(unsigned short));
+    L.bias1 = arena.alloc_floats((size_t)rows);
+    L.w1_exp = e;
+    spline_wide_image_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(L.W, L.bias, L.N_pad, L.K_pad, ldexpf(1.f, e), kOneAccActScale * ldexpf(1.f, e), L.W1, L.bias1, n);
+    FC_HIP(hipGetLastError());
+}
+
+extern int g_spline_ablate;
+
+void launch_spline_wide(const PackedLinear& L, const GemmEpi& e, int rows_alloc, hipStream_t s) {
+    if (!spline_wide_eligible(L, e.spline_K) || !e.A16 || e.a16_scale != kOneAccActScale || rows_alloc % 256 != 0 || !e.xbuf || !e.ldj_part ||
+        e.ldj_pitch < (size_t)rows_alloc || L.N_pad != spline_ncols(e.d2, 8))
+        throw Error(FC_ERR_INVALID, "launch_spline_wide: needs the one-accumulator activation image, the attached weight image and rows padded to 256");
+    SplineWideParams p{};
+    p.A16 = e.A16; p.W1 = L.W1; p.bias1 = L.bias1;
+    p.xbuf = e.xbuf; p.ldx = e.ldx; p.x2_col0 = e.x2_col0; p.d2 = e.d2; p.rows_valid = e.rows_valid;
+    p.ldj_part = e.ldj_part; p.ldj_pitch = e.ldj_pitch;
+    p.KT = L.K_pad / 32;
+    p.nbm = rows_alloc / 256;
+    p.ntile128 = L.N_pad / 128;
+    p.nbn = (p.ntile128 + 1) / 2;
+    p.col_group = (p.nbm % 8 == 0 && p.nbn > 5) ? 5 : 0;
+    p.out_scale = 1.0f / (kOneAccActScale * ldexpf(1.f, L.w1_exp));
+    p.ablate = g_spline_ablate;
+    static PerDeviceOnce attr_once, slots_once;
+    auto kern = spline_wide_kernel<1, 3, 3, 1, 2, 3, 3, 0>;
+    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS)); return 0; });
+    const int slots = slots_once.run([](int dev) {
+        int cus = 0;
+        FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int n = cus & ~7;                                         // one workgroup per CU, a multiple of 8 (XCD order)
+        return n < 8 ? 8 : n;
+    });
+    int grid = p.nbm * p.nbn;
+    if (grid > slots) grid = slots;
+    const double flops = 2.0 * (double)(e.rows_valid > 0 ? e.rows_valid : rows_alloc) * (double)(L.n_true ? L.n_true : L.N_pad) * (double)(L.k_true ? L.k_true : L.K_pad);
+    ProfScope ps("void fc::spline_wide_kernel<1, 3, 3, 1, 2, 3, 3, 0>(fc::SplineWideParams)", flops, 0.0, s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SW_LDS, s, p);
+    FC_HIP(hipGetLastError());
+}
+
+}  // namespace fc

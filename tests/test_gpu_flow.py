@@ -261,7 +261,7 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
     e0, e1 = torch.rand(B, M, 6, generator=g), torch.rand(B, N, 6, generator=g)
     eps = [torch.randn(B, N, 294, generator=g).to(DEV)]
     batch = (e0.to(DEV), e1.to(DEV), None)
-    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 2, 9: 1, 10: 1, 13: 4, 15: 2, 16: 1, 17: 0, 19: 0, 21: 0, 22: 1, 23: 1}
+    defaults = {0: 5, 3: 3, 5: 1, 7: 1, 8: 2, 9: 1, 10: 1, 13: 5, 15: 2, 16: 1, 17: 0, 19: 0, 21: 0, 22: 1, 23: 1}
 
     def run_with(knobs):
         """log-probs under the given knob values, or None when this build refuses one of them (a developer variant)"""
@@ -295,19 +295,25 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
         assert torch.equal(lp, ref), "the row-resident chain differs from the per-layer launches"
         lp = run_with({23: 2, 16: 0})
         assert lp is not None and (lp - ref).abs().max().item() < 5e-4
-        # every main loop of the fused spline GEMM issues the same MFMAs in the same k order and hands the same parameters to the same
+        # round 4: the shipped fused spline layer is the 256 x 256 one-accumulator kernel on 16x16x32 MFMAs (spline_wide.hip, knob 13 = 5): another
+        # arithmetic (one fp32 accumulator, unscaled low limbs, k32 MFMAs) than the 128 x 128 loops beside it -- same log-probs within fp32 noise
+        ref4 = run_with({13: 4})
+        err = (ref4 - ref).abs().max().item()
+        print(f"persistent 128x128 fused spline GEMM (knob 13 = 4): max |log-prob - default path| {err:.2e}")
+        assert err < 5e-4
+        # every main loop of the 128 x 128 family issues the same MFMAs in the same k order and hands the same parameters to the same
         # spline arithmetic: the register-staged loop (0), the LDS-DMA loops with the LDS parameter tile (1: 256x128, 2: 128x128), the
-        # transposed product evaluated from the accumulator registers with one tile per workgroup (3) and the shipped persistent form
+        # transposed product evaluated from the accumulator registers with one tile per workgroup (3) and the persistent form
         # (4) give bit-identical log-probs
         for v in (0, 1, 2, 3):
             lp = run_with({13: v})
             if lp is None:
                 continue
-            print(f"knob 13 = {v}: max |diff| {(lp - ref).abs().max().item():.3e}")
-            assert torch.equal(lp, ref), f"fused spline GEMM variant (knob 13 = {v}) differs from the shipped persistent loop"
-        lp = run_with({21: 1})                                    # rotated k order: another fp32 summation order, same sums
-        err = (lp - ref).abs().max().item()
-        print(f"persistent fused spline GEMM with rotated k loops: max |log-prob - default path| {err:.2e}")
+            print(f"knob 13 = {v}: max |diff| {(lp - ref4).abs().max().item():.3e}")
+            assert torch.equal(lp, ref4), f"fused spline GEMM variant (knob 13 = {v}) differs from the persistent 128x128 loop"
+        lp = run_with({13: 4, 21: 1})                             # rotated k order: another fp32 summation order, same sums
+        err = (lp - ref4).abs().max().item()
+        print(f"persistent fused spline GEMM with rotated k loops: max |log-prob - knob 13 = 4| {err:.2e}")
         assert err < 5e-4
         lp = run_with({22: 0})                                    # 128x128 tiles also for launches with few tiles (this test: 5 row tiles -> 64x64 tiles by default)
         assert torch.equal(lp, ref), "64x64 tiles for small launches changed the limb-chained GEMMs' results"
@@ -319,13 +325,15 @@ def test_every_kernel_variant_agrees_on_the_c2_layer_stack():
 
 
 def test_persistent_spline_gemm_walks_several_tiles_per_workgroup():
-    """The shipped fused spline GEMM is persistent (two workgroups per CU walk the tile list with one continuous DMA stream; results of a
-    tile are stored behind the next tile's first barrier).  18 row tiles x 30 column tiles = 540 tiles > 512 workgroup slots on the
-    plain tile order (row tiles not a multiple of 8), and 24 x 30 = 720 on the column-group order: every tile must come out exactly as
-    from the one-tile-per-workgroup kernels."""
+    """Both fused spline kernels are persistent.  The shipped 256 x 256 one-accumulator kernel (spline_wide.hip, knob 13 = 5) runs one workgroup
+    per CU over 256-row x 2-tile pairs with one continuous DMA stream: 19 row tiles x 15 pairs = 285 tiles > 256 slots on the plain tile
+    order, 24 x 15 = 360 on the column-group order (row tiles a multiple of 8) -- a scene's log-probs must not depend on where its tiles fall
+    (bit for bit the run of that scene alone, one tile per workgroup), and must agree with the 128 x 128 persistent loop (knob 13 = 4: two
+    workgroups per CU, 18 x 30 = 540 / 24 x 30 = 720 tiles) within fp32 noise.  That loop in turn must come out exactly as the
+    one-tile-per-workgroup kernels of its family."""
     from flowcompare_amd import engine
     lib = engine.lib()
-    for B, N in ((3, 768), (3, 1000)):                             # 2304 rows = 18 tiles; 3000 rows -> 24 tiles, 72 padding rows
+    for B, N in ((3, 768), (3, 1000), (3, 1600), (3, 2048)):       # 2304 rows; 3000 rows + 72 padding rows; 4800 rows = 19 tiles of 256; 6144 = 24
         cfg = fa.named_config("c2_dgcnn_attn_spline", n_flow_layers=2, sample_size=N)
         torch.manual_seed(21)
         md = fa.initialize_flow(cfg, device=DEV, mode="test")
@@ -339,13 +347,22 @@ def test_persistent_spline_gemm_walks_several_tiles_per_workgroup():
         batch = (e0.to(DEV), e1.to(DEV), None)
         try:
             _, ref, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+            _, again, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+            assert torch.equal(again, ref), f"{B} x {N}: the wide fused spline kernel is not deterministic"
+            _, solo, _ = fa.inner_loop((batch[0][1:2], batch[1][1:2], None), md, cfg, eps=[eps[0][1:2]])
+            assert torch.equal(solo[0], ref[1]), f"{B} x {N}: a scene's log-probs depend on the tiles it falls on (wide fused spline kernel)"
+            assert lib.fc_debug_set(13, 4) == 0
+            _, ref4, _ = fa.inner_loop(batch, md, cfg, eps=eps)
+            err = (ref4 - ref).abs().max().item()
+            print(f"{B} x {N}: wide kernel vs the 128 x 128 persistent loop: max |diff| {err:.2e}")
+            assert err < 1e-3
             for v in (3, 2):
                 if lib.fc_debug_set(13, v) != 0:                   # (3 = one tile per workgroup: a developer variant, refused by a default build)
                     continue
                 _, lp, _ = fa.inner_loop(batch, md, cfg, eps=eps)
-                assert torch.equal(lp, ref), f"{B} x {N}: persistent fused spline GEMM differs from knob 13 = {v}"
+                assert torch.equal(lp, ref4), f"{B} x {N}: persistent fused spline GEMM differs from knob 13 = {v}"
         finally:
-            lib.fc_debug_set(13, 4)
+            lib.fc_debug_set(13, 5)
         assert torch.isfinite(ref).all()
 
 
