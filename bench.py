@@ -415,7 +415,7 @@ def main():
                 if out is not None:
                     out["train"] = {"error": "training leg abandoned after 240 s"}
                     print(json.dumps(out), flush=True)
-                os._exit(0 if out is not None else 3)
+                os._exit(4)                               # non-zero on EVERY rank: the forward numbers are in the JSON line, not in the exit status
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             torch.cuda.reset_peak_memory_stats()

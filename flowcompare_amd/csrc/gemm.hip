@@ -1310,13 +1310,14 @@ bool Fp16Guard::overflowed() {
 
 // ---- deferred range check (common.h).  Per thread: the switch, the queued passes and a pool of pinned flag slots / events.
 namespace {
-struct DeferredPass { std::function<void()> rerun; int* dev_flag; hipStream_t stream; int* host_flag; hipEvent_t ev; };
+struct DeferredPass { std::function<void()> rerun; int* dev_flag; hipStream_t stream; int* host_flag; hipEvent_t ev; int device; };
 struct DeferState {
     bool on = false;
     std::vector<DeferredPass> pending;
-    std::vector<std::pair<int*, hipEvent_t>> pool;
+    struct Slot { int* host_flag; hipEvent_t ev; int device; };      // (an event belongs to the device that was current when it was created)
+    std::vector<Slot> pool;
     ~DeferState() {
-        for (auto& pe : pool) { (void)hipHostFree(pe.first); (void)hipEventDestroy(pe.second); }
+        for (auto& pe : pool) { (void)hipHostFree(pe.host_flag); (void)hipEventDestroy(pe.ev); }
         for (auto& d : pending) { (void)hipHostFree(d.host_flag); (void)hipEventDestroy(d.ev); }
     }
 };
@@ -1328,9 +1329,15 @@ void guard_set_deferred(bool on) { t_defer.on = on; }
 void Fp16Guard::defer(std::function<void()> rerun) {
     t_fp16_flag = nullptr;
     open = false;
-    DeferredPass d{std::move(rerun), flag, stream, nullptr, nullptr};
-    if (!t_defer.pool.empty()) { d.host_flag = t_defer.pool.back().first; d.ev = t_defer.pool.back().second; t_defer.pool.pop_back(); }
-    else {
+    DeferredPass d{std::move(rerun), flag, stream, nullptr, nullptr, 0};
+    FC_HIP(hipGetDevice(&d.device));                 // the pass may be repeated from a call made with another device current
+    for (size_t i = t_defer.pool.size(); i-- > 0;)
+        if (t_defer.pool[i].device == d.device) {
+            d.host_flag = t_defer.pool[i].host_flag; d.ev = t_defer.pool[i].ev;
+            t_defer.pool.erase(t_defer.pool.begin() + (long)i);
+            break;
+        }
+    if (!d.host_flag) {
         FC_HIP(hipHostMalloc((void**)&d.host_flag, sizeof(int), hipHostMallocDefault));
         FC_HIP(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
     }
@@ -1344,9 +1351,13 @@ int guard_resolve() {
     std::vector<DeferredPass> todo;
     todo.swap(t_defer.pending);
     std::exception_ptr err;
+    int dev_entry = 0;
+    (void)hipGetDevice(&dev_entry);
     for (DeferredPass& d : todo) {
         try {
+            if (err) (void)hipEventSynchronize(d.ev);        // error path: the flag copy behind this event still targets d.host_flag -- wait before the slot is pooled
             if (!err) {
+                FC_HIP(hipSetDevice(d.device));              // re-launches go to the device (and pointers) the pass was queued on
                 FC_HIP(hipEventSynchronize(d.ev));
                 if (*d.host_flag) {                          // the fast pass left fp16's range: the whole pass again on the bf16-limb loops
                     g_fp16_fallbacks.fetch_add(1);
@@ -1360,8 +1371,9 @@ int guard_resolve() {
                 }
             }
         } catch (...) { err = std::current_exception(); }
-        t_defer.pool.emplace_back(d.host_flag, d.ev);
+        t_defer.pool.push_back({d.host_flag, d.ev, d.device});
     }
+    (void)hipSetDevice(dev_entry);
     if (err) std::rethrow_exception(err);
     return repeated;
 }
@@ -1448,6 +1460,8 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
         if (e.gradu && (!e.C || e.C16 || e.Cpre || e.act != FC_ACT_NONE || e.ldgu < L.N_pad || (e.gact != FC_ACT_GELU && e.gact != FC_ACT_RELU && e.gact != FC_ACT_ELU)))
             throw Error(FC_ERR_INVALID, "launch_gemm: an activation-gradient epilogue goes with an fp32 C, no activation, and GELU / RELU / ELU");
         if (e.Cpre && (!e.C || e.C16)) throw Error(FC_ERR_INVALID, "launch_gemm: a pre-activation output goes with an fp32 C and no limb image");
+        if ((e.gradu || e.Cpre) && kDevVariants && (v_variant == 0 || v_variant == 1 || (v_variant == 5 && v_bigtile == 3 && g_gemm_prefetch3)))
+            throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: the training epilogues (Cpre / gradu) exist on VAR 2 / 3 / 5 only; this developer variant would ignore them");
         if (e.C16 && !(f16 && v_bigtile == 3 && L.N_pad > 64 && L.N_pad % 16 == 0))
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: limb-image output exists on the eight-wave split-fp16 tile only");
         if (e.a16_scale != 0.f) throw Error(FC_ERR_INVALID, "launch_gemm: a one-accumulator activation image is an input of the fused spline layer only");

@@ -23,8 +23,10 @@
 //     store instruction); the last layer writes the row-major limb image [row][K/16][hi 16 | lo' 16] (GemmEpi::A16) that the fused
 //     spline / affine output GEMM copies.
 // Arithmetic is the split-fp16 GEMM's (same limb split, same k order, same three products per block into main / cross accumulators,
-// same GELU); the residual is added in the epilogue instead of the accumulator init, so results agree with the separate launches to
-// fp32 rounding, not bit for bit.
+// same GELU, the residual added behind the k loop in both): results are BIT-IDENTICAL to the per-layer launches the engine takes for
+// small batches (tests/test_gpu_flow.py::test_every_kernel_variant_agrees..., torch.equal), so a scene's log-probs do not depend on
+// the batch it sits in.  Round 4: the last layer's limb split takes run-time scales (MlpRowsParams::out_s1 / out_s2) so that it can
+// write the one-accumulator image of the wide fused spline kernel (spline_wide.hip); (1, 2048) reproduces the fixed form's bits.
 #include "common.h"
 #include "activations.h"
 #include "mlprows.h"

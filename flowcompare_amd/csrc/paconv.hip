@@ -14,15 +14,24 @@
 
 namespace fc {
 
+// Squared distance as the reference's kernels compute it: lib/pointops/setup.py:32-33 builds them with `nvcc -O2`, whose default -fmad=true
+// contracts `(dx)*(dx) + (dy)*(dy) + (dz)*(dz)` (sampling_cuda_kernel.cu:93, knnquery_heap_cuda_kernel.cu:77, interpolation_cuda_kernel.cu:155)
+// into one multiply and two fused multiply-adds.  This file is compiled with -ffp-contract=off: the fusions are explicit, and identical to
+// oracle/pointops_oracle.c's.  (Round 3 rounded every square separately: FPS picks, the 32-NN boundary and 3-NN weights could differ from
+// the kernels' at near-ties.)
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
-    return (dx * dx + dy * dy) + dz * dz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
 
 // ---------------------------------------------------------------- furthest point sampling
 // One workgroup (1024 threads) per scene; xyz and the running min-distance live in LDS.  The arg-max reproduces the CUDA
-// kernel's tie rule: virtual thread t (t < T = opt_n_threads(n)) scans k = t, t+T, ... keeping its FIRST maximum, and among
-// threads the LOWER thread id wins ties.
+// kernel's tie rule: virtual thread t (t < T = opt_n_threads(n)) scans k = t, t+T, ... keeping its FIRST maximum; among threads the
+// kernel's shared-memory tree (sampling_cuda_kernel.cu:47-53, 100-160: levels s = T/2 ... 1, slot t takes slot t + s only when STRICTLY
+// greater) decides.  Two tied threads meet at the level of their LOWEST differing bit and the one whose bit is 0 stays: the winner is the
+// thread with the smallest BIT-REVERSED id -- not the lowest id (round 3's reading; the literal simulation in oracle/pointops_oracle.c
+// showed the difference on a lattice: after picks {0, 255} of an 8 x 8 x 4 grid the maxima sit at threads 29, 30, 225, 226 and the kernel
+// takes 226).  (value, bit-reversed id) is a total order, so any reduction order finds that winner.
 // BIG (more than 8192 points per scene: the LDS image would not fit): coordinates are read from the input rows and the running
 // min-distance lives in a caller-provided global scratch [B][n]; both stay L2-resident over the m sweeps (same arithmetic, same ties).
 template <bool BIG>
@@ -36,6 +45,7 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
     float* st = BIG ? scratch + (size_t)b * n : sm + 3 * n; // [n]
     __shared__ float red_v[16];
     __shared__ int red_i[16];
+    __shared__ int red_t[16];
     __shared__ int s_old;
     for (int k = tid; k < n; k += 1024) {
         if (!BIG) { sm[3 * k] = src[(size_t)k * ld]; sm[3 * k + 1] = src[(size_t)k * ld + 1]; sm[3 * k + 2] = src[(size_t)k * ld + 2]; }
@@ -55,25 +65,25 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
                 st[k] = d2;
                 if (d2 > best) { best = d2; besti = k; }
             }
-        int bt = tid;                                       // owning thread: ties go to the LOWER thread id (the CUDA tree keeps idx1)
+        unsigned bt = __brev((unsigned)tid);                // owning thread, bit-reversed: the CUDA tree's tie order (above)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const float ov = __shfl_xor(best, off, 64);
             const int oi = __shfl_xor(besti, off, 64);
-            const int ot = __shfl_xor(bt, off, 64);
+            const unsigned ot = (unsigned)__shfl_xor((int)bt, off, 64);
             if (ov > best || (ov == best && ot < bt)) { best = ov; besti = oi; bt = ot; }
         }
-        if (lane == 0) { red_v[wave] = best; red_i[wave] = besti; }
+        if (lane == 0) { red_v[wave] = best; red_i[wave] = besti; red_t[wave] = (int)bt; }
         __syncthreads();
         if (wave == 0) {
             float v = lane < 16 ? red_v[lane] : -2.f;
             int i = lane < 16 ? red_i[lane] : 0;
-            int w2 = lane;                                  // wave order == thread order
+            unsigned w2 = lane < 16 ? (unsigned)red_t[lane] : 0xffffffffu;
 #pragma unroll
             for (int off = 8; off >= 1; off >>= 1) {
                 const float ov = __shfl_xor(v, off, 64);
                 const int oi = __shfl_xor(i, off, 64);
-                const int ow = __shfl_xor(w2, off, 64);
+                const unsigned ow = (unsigned)__shfl_xor((int)w2, off, 64);
                 if (ov > v || (ov == v && ow < w2)) { v = ov; i = oi; w2 = ow; }
             }
             if (lane == 0) { s_old = i; idx[(size_t)b * m + j] = i; }
@@ -128,6 +138,11 @@ void launch_gather_xyz(const float* src, int ld, const int32_t* idx, float* dst,
 // wave extracts the global k best by k rounds of (distance, index)-lexicographic arg-min: the result is exactly the first k
 // entries of a stable ascending sort, i.e. the heap kernel's output whenever distances are distinct.  n < k: the tail keeps
 // index 0 like the reference's untouched heap slots.
+// EQUAL distances (lattice clouds, duplicated points): the reference's max-heap (knnquery_heap_cuda_kernel.cu:21-49: strict `d2 < root`
+// insertion, reheap, heap sort) returns them in the HEAP's order, and which of several entries tied at the k-th distance survives an
+// eviction is the heap's choice too -- neither is an index order.  The wave therefore extracts one candidate more than k, and when any two
+// neighbouring distances among those k + 1 are equal its lane 0 re-runs the query through the kernel's own heap, literally (LDS arrays):
+// same set, same order as the reference on every input.  Clouds without exact ties never take that path.
 template <int LK>   // per-lane list length
 __global__ __launch_bounds__(256) void knn_xyz_kernel(const float* __restrict__ xyz, int ld, const float* __restrict__ qxyz, int32_t* __restrict__ out,
                                                       int n, int m, int k, int total) {
@@ -153,7 +168,10 @@ __global__ __launch_bounds__(256) void knn_xyz_kernel(const float* __restrict__ 
     }
     int32_t* o = out + (size_t)q * k;
     const int kk = k < n ? k : n;
-    for (int r = 0; r < kk; ++r) {
+    const int kx = kk < n ? kk + 1 : kk;                   // one more than k: a tie across the k-th boundary counts
+    bool tie = false;
+    float prev = -1.f;
+    for (int r = 0; r < kx; ++r) {
         float v = bd[0];
         int i = bi[0];
 #pragma unroll
@@ -167,9 +185,41 @@ __global__ __launch_bounds__(256) void knn_xyz_kernel(const float* __restrict__ 
             for (int t = 0; t + 1 < LK; ++t) { bd[t] = bd[t + 1]; bi[t] = bi[t + 1]; }
             bd[LK - 1] = INFINITY; bi[LK - 1] = 0x7fffffff;
         }
-        if (lane == 0) o[r] = i;
+        tie = tie || v == prev;
+        prev = v;
+        if (lane == 0 && r < kk) o[r] = i;
     }
     if (lane >= kk && lane < k) o[lane] = 0;
+    if (tie) {                                             // (wave-uniform) the reference's heap, literally, by lane 0
+        __shared__ float hd_all[4][32];
+        __shared__ int hi_all[4][32];
+        if (lane == 0) {
+            float* hd = hd_all[threadIdx.x >> 6];
+            int* hi = hi_all[threadIdx.x >> 6];
+            auto reheap = [&](int kh) {
+                int root = 0, child = 1;
+                while (child < kh) {
+                    if (child + 1 < kh && hd[child + 1] > hd[child]) child++;
+                    if (hd[root] > hd[child]) return;
+                    const float td = hd[root]; hd[root] = hd[child]; hd[child] = td;
+                    const int ti = hi[root]; hi[root] = hi[child]; hi[child] = ti;
+                    root = child;
+                    child = root * 2 + 1;
+                }
+            };
+            for (int t = 0; t < k; ++t) { hd[t] = 1e10f; hi[t] = 0; }
+            for (int c = 0; c < n; ++c) {
+                const float d2 = sqdist3(qx, qy, qz, src[(size_t)c * ld], src[(size_t)c * ld + 1], src[(size_t)c * ld + 2]);
+                if (d2 < hd[0]) { hd[0] = d2; hi[0] = c; reheap(k); }
+            }
+            for (int t = k - 1; t > 0; --t) {
+                const float td = hd[0]; hd[0] = hd[t]; hd[t] = td;
+                const int ti = hi[0]; hi[0] = hi[t]; hi[t] = ti;
+                reheap(t);
+            }
+            for (int t = 0; t < k; ++t) o[t] = hi[t];
+        }
+    }
 }
 void launch_knn_xyz(const float* xyz, int ld, const float* qxyz, int32_t* out, int B, int n, int m, int k, hipStream_t s) {
     const int total = B * m;

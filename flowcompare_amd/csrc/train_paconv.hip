@@ -22,7 +22,7 @@ void launch_paconv_group(const float* xyz, int ldxyz, const float* feat, int ldf
 
 __device__ __forceinline__ float sqd3(float ax, float ay, float az, float bx, float by, float bz) {
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
-    return (dx * dx + dy * dy) + dz * dz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));       // nvcc -O2 contracts the kernels' sum of squares (paconv.hip sqdist3, oracle/pointops_oracle.c)
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -120,9 +120,18 @@ class GradientReducer:
         self.pending = [len(b) for b in self.buckets]
         self.inflight = [None] * len(self.buckets)
         self.present = [0.0] * len(self.params)
+        self.next_bucket = 0
 
     def _launch(self, i):
         self.inflight[i] = dist.all_reduce(self.flat[i], group=self.group, async_op=True)
+
+    def _launch_ready(self):
+        """Collectives must be issued in ONE order on every rank, whatever each rank's own gradient pattern: buckets start strictly in bucket
+        order, a complete bucket waits for the ones before it (a bucket holding a parameter without a gradient on this rank only completes
+        in finish()).  Backward fills the buckets in that same order, so the overlap with backward is unchanged in the common case."""
+        while self.next_bucket < len(self.buckets) and self.pending[self.next_bucket] == 0:
+            self._launch(self.next_bucket)
+            self.next_bucket += 1
 
     def _on_grad(self, p):
         if p.grad is None or p.grad.data_ptr() != self.views[id(p)].data_ptr():
@@ -135,32 +144,35 @@ class GradientReducer:
         i = self.bucket_of[id(p)]
         self.pending[i] -= 1
         if self.pending[i] == 0:
-            self._launch(i)
+            self._launch_ready()
 
     def finish(self):
         """Waits for every bucket (launching those whose parameters received no gradient this step, as zeros, so that all ranks issue
         the same collectives); afterwards every .grad view holds the sum over ranks, and parameters without a gradient on any rank have
-        .grad = None again.  The presence mask is all-reduced every step (one tiny asynchronous collective, so every rank issues the same
-        sequence whatever its own pattern) but read back to the host -- the only host synchronisation of the step -- only when this
-        rank's own pattern differs from the one its cached answer belongs to: the set of gradient-less parameters is a property of the
-        graph, not of the data, so in the steady state finish() never waits for the device."""
-        for i in range(len(self.buckets)):
-            if self.inflight[i] is None:
-                self._launch(i)
+        .grad = None again.  The presence mask is all-reduced (MAX) every step together with one more number: "my own pattern differs from
+        the one of my previous step".  Every rank reads that reduced flag back (4 bytes: the step's only host synchronisation, behind a
+        backward of ~1 s) and re-reads the reduced mask when ANY rank's pattern changed -- a cache keyed on the local pattern alone would
+        keep a stale `absent` list on the ranks whose own pattern did not move while another rank's did, and FlatAdam would then update a
+        parameter on some replicas and skip it on others (round-3 advisor finding)."""
+        for i in range(self.next_bucket, len(self.buckets)):
+            self._launch(i)
+        self.next_bucket = len(self.buckets)
         pattern = tuple(self.present)
         cached = getattr(self, "_mask_cache", None)
-        if cached is None or cached[0] != pattern:
-            local = torch.tensor(self.present, dtype=torch.float32).to(self.flat[0].device)
+        changed = cached is None or cached[0] != pattern
+        if changed:
+            local = torch.tensor(self.present + [1.0], dtype=torch.float32).to(self.flat[0].device)
         else:
-            local = cached[1]
+            local = cached[1]                                     # (same pattern, flag 0: the device copy of the previous step)
         mask = local.clone()
         work = dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for w in self.inflight:
             w.wait()
         work.wait()
-        if cached is None or cached[0] != pattern:
-            absent = [m == 0.0 for m in mask.cpu().tolist()]
-            self._mask_cache = (pattern, local, absent)
+        if bool(mask[-1].item() != 0.0) or cached is None:        # some rank's pattern changed: every rank re-reads the reduced mask
+            absent = [m == 0.0 for m in mask[:-1].cpu().tolist()]
+            steady = torch.tensor(self.present + [0.0], dtype=torch.float32).to(self.flat[0].device)
+            self._mask_cache = (pattern, steady, absent)
         self.absent = self._mask_cache[2]
         for p, a in zip(self.params, self.absent):
             if a:

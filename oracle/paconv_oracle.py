@@ -5,7 +5,7 @@ Parity status, per part:
     ScoreNet / weight-bank maths, SharedMLP, feature propagation and the head MLP — the fixtures are produced by running the
     reference's own Python classes (PointNet2SSGSeg.forward etc.) on CPU;
   * restated from the reference's CUDA sources and NOT runnable here (the reference needs a CUDA device for them, SURVEY.md
-    F9): the six pointops kernels below.  For the golden run they are substituted INTO the reference by gen_golden.py, so the
+    F9): the six pointops kernels below (the three with arithmetic and tie rules literally, in C: oracle/pointops_oracle.c).  For the golden run they are substituted INTO the reference by gen_golden.py, so the
     fixtures pin everything around them but the kernels themselves are "parity unpinned" at reference level (no golden
     vectors exist for them in the reference).  Each cites the .cu lines it follows.
 
@@ -18,6 +18,43 @@ import torch.nn.functional as F
 
 
 # ------------------------------------------------------------------ the six pointops kernels (CUDA in the reference)
+# Three of them carry arithmetic and tie rules (furthest point sampling, heap k-NN, three nearest neighbours): those are restated LITERALLY in C
+# (oracle/pointops_oracle.c: the kernels' loops, their max-heap, the distance as nvcc's default -fmad=true contracts it) and called through
+# ctypes; the library is built on first use with gcc (-ffp-contract=off: every fusion is explicit in the source).  Round 3's torch versions
+# (separately rounded squares, stable argsort instead of the heap's order) deviated from the kernels in exactly those two points.
+_LIB = None
+
+
+def _pointops_lib():
+    global _LIB
+    if _LIB is None:
+        import ctypes
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        src, out = os.path.join(here, "pointops_oracle.c"), os.path.join(here, "_build", "libpointops_oracle.so")
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            tmp = f"{out}.{os.getpid()}.tmp"
+            subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", tmp, src, "-lm"], check=True)
+            os.replace(tmp, out)
+        _LIB = ctypes.CDLL(out)
+    return _LIB
+
+
+def _suffix(t):
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == torch.float64:
+        return "f64"
+    raise TypeError(f"pointops oracle: float32 or float64, got {t.dtype}")
+
+
+def _p(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def opt_n_threads(n):
     """lib/pointops/src/cuda_utils.h:15-18."""
     return max(min(1 << int(math.log(n) / math.log(2.0)), 1024), 1)
@@ -26,26 +63,14 @@ def opt_n_threads(n):
 def furthest_sampling(xyz, m):
     """lib/pointops/src/sampling/sampling_cuda_kernel.cu:58-168.  xyz [B,n,3] -> idx [B,m] (int64).
     Start at index 0; temp = min(temp, d); arg-max with the kernel's tie rule: thread t scans k = t, t+T, ... keeping the FIRST
-    maximum (strict >), the shared-memory tree keeps the LOWER thread on ties -> winner = min over (k mod T, k) among maxima."""
+    maximum (strict >), the shared-memory tree keeps the LOWER thread on ties (pointops_oracle.c fps_*: the block simulated thread by thread)."""
     B, n, _ = xyz.shape
-    T = opt_n_threads(n)
-    idx = torch.zeros(B, max(m, 0), dtype=torch.long)
+    idx = torch.zeros(B, max(m, 0), dtype=torch.int32)
     if m <= 0:
-        return idx
-    k = torch.arange(n)
-    key = (k % T) * n + k
-    for b in range(B):
-        temp = torch.full((n,), 1e10, dtype=xyz.dtype)
-        old = 0
-        for j in range(1, m):
-            d = ((xyz[b] - xyz[b, old]) ** 2)
-            d = (d[:, 0] + d[:, 1]) + d[:, 2]
-            temp = torch.minimum(d, temp)
-            best = temp.max()
-            cand = torch.nonzero(temp == best)[:, 0]
-            old = int(cand[key[cand].argmin()])
-            idx[b, j] = old
-    return idx
+        return idx.long()
+    x = xyz.detach().contiguous()
+    getattr(_pointops_lib(), "fps_" + _suffix(x))(B, n, m, _p(x), _p(idx))
+    return idx.long()
 
 
 def gathering(feat_cf, idx):
@@ -54,16 +79,18 @@ def gathering(feat_cf, idx):
 
 
 def knnquery_heap(nsample, xyz, new_xyz):
-    """lib/pointops/src/knnquery_heap/knnquery_heap_cuda_kernel.cu:53-89: nsample nearest of xyz [B,n,3] for every new_xyz
-    [B,m,3], ascending squared distance; when n < nsample the unfilled heap slots keep (1e10, index 0)."""
+    """lib/pointops/src/knnquery_heap/knnquery_heap_cuda_kernel.cu:21-89: nsample nearest of xyz [B,n,3] for every new_xyz [B,m,3] through
+    the kernel's max-heap (strict `d2 < root` insertion, heap sort): ascending squared distance, equal distances in the HEAP's order; when
+    n < nsample the unfilled slots keep (1e10, index 0) and sort to the end."""
     B, n, _ = xyz.shape
-    d = (new_xyz[:, :, None, :] - xyz[:, None, :, :]) ** 2
-    d = (d[..., 0] + d[..., 1]) + d[..., 2]
-    order = torch.argsort(d, dim=-1, stable=True)
-    if n >= nsample:
-        return order[..., :nsample]
-    pad = torch.zeros(B, new_xyz.shape[1], nsample - n, dtype=torch.long)
-    return torch.cat((order, pad), -1)
+    m = new_xyz.shape[1]
+    x, q = xyz.detach().contiguous(), new_xyz.detach().contiguous()
+    idx = torch.zeros(B, m, nsample, dtype=torch.int32)
+    d2 = torch.zeros(B, m, nsample, dtype=x.dtype)
+    rc = getattr(_pointops_lib(), "knn_heap_" + _suffix(x))(B, n, m, nsample, _p(x), _p(q), _p(idx), _p(d2))
+    if rc != 0:
+        raise ValueError("knnquery_heap: nsample must be 1..100 (the kernel's fixed arrays)")
+    return idx.long()
 
 
 def grouping(feat_cf, idx):
@@ -75,16 +102,14 @@ def grouping(feat_cf, idx):
 
 def nearest_neighbor3(unknown, known):
     """lib/pointops/src/interpolation/interpolation_cuda_kernel.cu:134-176 (+ sqrt in functions/pointops.py:112): the 3 nearest
-    known points (strict '<' updates -> earliest index wins ties), best values kept in double, returned as float sqrt."""
-    d = (unknown[:, :, None, :] - known[:, None, :, :]) ** 2
-    d = (d[..., 0] + d[..., 1]) + d[..., 2]
-    m = known.shape[1]
-    if m < 3:
-        d = torch.cat((d, torch.full(d.shape[:2] + (3 - m,), float("inf"), dtype=d.dtype)), -1)   # best stays 1e40 -> float inf, idx 0
-    order = torch.argsort(d, dim=-1, stable=True)[..., :3]
-    dist2 = torch.gather(d, 2, order)
-    order = torch.where(torch.isinf(dist2), torch.zeros_like(order), order)
-    return torch.sqrt(dist2), order
+    known points (strict '<' updates -> earliest index wins ties), best values kept in double, returned as float sqrt; with fewer than three
+    known points the unfilled slots stay (1e40 -> +inf as float, index 0)."""
+    B, n, _ = unknown.shape
+    u, k = unknown.detach().contiguous(), known.detach().contiguous()
+    d2 = torch.zeros(B, n, 3, dtype=u.dtype)
+    idx = torch.zeros(B, n, 3, dtype=torch.int32)
+    getattr(_pointops_lib(), "three_nn_" + _suffix(u))(B, n, known.shape[1], _p(u), _p(k), _p(d2), _p(idx))
+    return torch.sqrt(d2), idx.long()
 
 
 def interpolation(feat_cf, idx, weight):

@@ -90,7 +90,7 @@ def test_full_size_rows_match_the_oracle_end_to_end_with_its_own_embedder(c2):
     lp32, dec32 = oracle_flow_rows_forced(cfg, md, ctx32, e1[:1, :n], None, [eps[:1, :n]], torch.float32)
     lp64_ref, _ = oracle_flow_rows_forced(cfg, md, ctx64, e1[:1, :n], None, [eps[:1, :n]], torch.float64, forced=dec32)
     print(f"oracle: {time.time() - t0:.0f} s of host time")
-    check_spline_rows_against_fp64("C2 end to end (oracle's own fp64 embedder), scene 0 rows 0..255", lp_rows, dec_hip, lp64_hip, None, None, lp32, lp64_ref)
+    check_spline_rows_against_fp64("C2 end to end (oracle's own fp64 embedder), scene 0 rows 0..255", lp_rows, dec_hip, lp64_hip, None, None, lp32, lp64_ref, end_to_end=True)
 
 
 def test_full_size_embedder_matches_fp64_oracle(c2):

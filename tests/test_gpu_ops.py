@@ -299,6 +299,131 @@ def test_fps_ties_on_a_grid():
     assert torch.equal(idx, P.furthest_sampling(g, 64))
 
 
+def _pointops_clouds():
+    """Clouds that exercise what random floats never do: an integer lattice (exact distance ties everywhere), duplicated points (ties at
+    distance 0: which copy is the centre), a non-cubic lattice with a jitter that breaks SOME ties, and plain random points."""
+    lat = torch.stack(torch.meshgrid(torch.arange(8.), torch.arange(8.), torch.arange(8.), indexing="ij"), -1).reshape(1, -1, 3)
+    g = torch.Generator().manual_seed(5)
+    rnd = torch.rand(1, 512, 3, generator=g)
+    dup = rnd.clone()
+    dup[:, 1::4] = dup[:, 0::4]                                   # every 4th point is a copy of its predecessor
+    mixed = (lat * torch.tensor([1.0, 0.5, 0.25])).clone()
+    mixed[:, ::7] += 1e-3 * torch.rand(1, mixed[:, ::7].shape[1], 3, generator=g)
+    return {"lattice": lat, "duplicates": dup, "lattice+jitter": mixed, "random": rnd}
+
+
+def _knn_hip(xyz, q, k):
+    """fc_op_paconv_knn_f32 on [B, n, 3] / [B, m, 3] clouds (the C ABI takes rows of pitch 4) -> [B, m, k] local indices"""
+    L = engine.lib()
+    B, n, m = xyz.shape[0], xyz.shape[1], q.shape[1]
+    x4 = torch.zeros(B * n, 4); x4[:, :3] = xyz.reshape(-1, 3)
+    q4 = torch.zeros(B * m, 4); q4[:, :3] = q.reshape(-1, 3)
+    x4, q4 = x4.to(DEV), q4.to(DEV)
+    out = torch.full((B * m, k), -1, dtype=torch.int32, device=DEV)
+    with torch.cuda.device(DEV):
+        engine._check(L.fc_op_paconv_knn_f32(engine._ptr(x4), engine._ptr(q4), engine._ptr(out), B, n, m, k, engine._stream()))
+    return out.cpu().long().reshape(B, m, k)
+
+
+@pytest.mark.parametrize("cloud", ["lattice", "duplicates", "lattice+jitter", "random"])
+@pytest.mark.parametrize("k", [32, 8])
+def test_paconv_knn_ties_follow_the_reference_heap(cloud, k):
+    """fc_op_paconv_knn_f32 against the literal restatement of knnquery_heap_cuda_kernel.cu:21-89 (oracle/pointops_oracle.c: the kernel's
+    max-heap, strict `d2 < root` insertion, heap sort; distances as nvcc -O2 contracts them): identical SET and identical ORDER, also where
+    distances tie -- the heap's order among equal distances is not an index order, and which entry tied at the k-th distance survives is
+    the heap's choice.  Queries: every 4th point (the lattice's and the copies' own points: distance 0 ties included)."""
+    from oracle import paconv_oracle as P
+    xyz = _pointops_clouds()[cloud]
+    xyz = torch.cat((xyz, xyz.flip(1)), 0)                       # B = 2: the second scene walks the candidates in the opposite order
+    q = xyz[:, ::4].contiguous()
+    got = _knn_hip(xyz, q, k)
+    ref = P.knnquery_heap(k, xyz, q)
+    bad = (got != ref).any(-1)
+    assert not bad.any(), f"{cloud}, k = {k}: {int(bad.sum())} of {bad.numel()} queries differ from the reference heap, first: {got[bad][0].tolist()} vs {ref[bad][0].tolist()}"
+    if cloud == "lattice":
+        srt = torch.argsort(((q[:, :, None] - xyz[:, None]) ** 2).sum(-1), dim=-1, stable=True)[..., :k]
+        assert (srt != ref).any(), "the lattice case no longer distinguishes the heap's order from a stable sort"
+
+
+@pytest.mark.parametrize("n,m,k", [(20, 5, 32), (3, 3, 32), (1, 1, 8), (33, 9, 32)])
+def test_paconv_knn_fewer_points_than_neighbours(n, m, k):
+    """n < nsample: the reference's unfilled heap slots keep (1e10, index 0) and sort to the end (knnquery_heap_cuda_kernel.cu:69-72)."""
+    from oracle import paconv_oracle as P
+    xyz = _rand(2, n, 3, seed=31)
+    q = xyz[:, :m].contiguous()
+    assert torch.equal(_knn_hip(xyz, q, k), P.knnquery_heap(k, xyz, q))
+
+
+def test_paconv_knn_at_16384_points():
+    """The size of C5's first set-abstraction level: 16384 candidates, 4096 queries picked by farthest point sampling, 32 neighbours."""
+    from oracle import paconv_oracle as P
+    xyz = _rand(1, 16384, 3, seed=32)
+    idx = engine.op_fps(xyz.to(DEV), 4096).cpu().long()
+    assert torch.equal(idx, P.furthest_sampling(xyz, 4096))
+    q = torch.gather(xyz, 1, idx[..., None].expand(-1, -1, 3))
+    assert torch.equal(_knn_hip(xyz, q, 32), P.knnquery_heap(32, xyz, q))
+
+
+def _three_nn_hip(unknown, known):
+    L = engine.lib()
+    B, nu, mk = unknown.shape[0], unknown.shape[1], known.shape[1]
+    u4 = torch.zeros(B * nu, 4); u4[:, :3] = unknown.reshape(-1, 3)
+    k4 = torch.zeros(B * mk, 4); k4[:, :3] = known.reshape(-1, 3)
+    u4, k4 = u4.to(DEV), k4.to(DEV)
+    idx = torch.full((B * nu, 3), -1, dtype=torch.int32, device=DEV)
+    w = torch.full((B * nu, 3), float("nan"), dtype=torch.float32, device=DEV)
+    with torch.cuda.device(DEV):
+        engine._check(L.fc_train_three_nn_f32(engine._ptr(u4), engine._ptr(k4), B, nu, mk, engine._ptr(idx), engine._ptr(w), engine._stream()))
+    idx = idx.cpu().long().reshape(B, nu, 3) - (torch.arange(B) * mk)[:, None, None]      # the entry point returns rows of the whole [B * mk] panel
+    return idx, w.cpu().reshape(B, nu, 3)
+
+
+def _three_nn_ref(unknown, known):
+    """nearestneighbor (interpolation_cuda_kernel.cu:134-176) + PointNet2FPModule's weights (pointnet2_paconv_modules.py:224-228)"""
+    from oracle import paconv_oracle as P
+    dist, idx = P.nearest_neighbor3(unknown, known)
+    rec = 1.0 / (dist + 1e-8)
+    return idx, rec / rec.sum(dim=2, keepdim=True)
+
+
+@pytest.mark.parametrize("cloud", ["lattice", "duplicates", "lattice+jitter", "random"])
+def test_three_nn_matches_the_reference_kernel(cloud):
+    """fc_train_three_nn_f32 (and the forward's three_nn_interp_kernel, same selection code) against the literal restatement of
+    nearestneighbor_cuda_kernel_fast: three running minima with strict `<` updates (the earliest index wins a tie), distances contracted as
+    nvcc -O2 does; inverse-distance weights of PointNet2FPModule.  Known points: every 4th point of the cloud (so unknown points coincide
+    with known ones: distance 0, weight 1e8 / sum)."""
+    xyz = _pointops_clouds()[cloud]
+    xyz = torch.cat((xyz, xyz.flip(1)), 0)
+    known = xyz[:, ::4].contiguous()
+    idx, w = _three_nn_hip(xyz, known)
+    ridx, rw = _three_nn_ref(xyz, known)
+    assert torch.equal(idx, ridx), f"{cloud}: {int((idx != ridx).any(-1).sum())} of {idx.shape[0] * idx.shape[1]} points pick other neighbours"
+    assert (w - rw).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("nu,mk", [(5, 1), (20, 2), (64, 3), (16384, 4096)])
+def test_three_nn_with_fewer_than_three_known_points_and_at_size(nu, mk):
+    """m < 3: the kernel's unfilled minima stay 1e40 -> +inf as float, index 0, weight 0 (interpolation_cuda_kernel.cu:150-151, 169-175); and
+    the size of C5's last feature-propagation level."""
+    unknown, known = _rand(2 if nu < 1000 else 1, nu, 3, seed=41), None
+    known = unknown[:, :mk].contiguous() if mk < 100 else _rand(1, mk, 3, seed=42)
+    idx, w = _three_nn_hip(unknown, known)
+    ridx, rw = _three_nn_ref(unknown, known)
+    assert torch.equal(idx, ridx)
+    assert torch.isfinite(w).all() and (w - rw).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("cloud", ["lattice", "duplicates", "lattice+jitter"])
+def test_fps_ties_on_degenerate_clouds(cloud):
+    """Farthest point sampling on clouds with exact ties (and, with duplicated points, minimum distances of exactly 0): the reference block's
+    (k mod T, k) tie rule, simulated thread by thread in oracle/pointops_oracle.c."""
+    from oracle import paconv_oracle as P
+    xyz = _pointops_clouds()[cloud]
+    xyz = torch.cat((xyz, xyz.flip(1)), 0)
+    m = xyz.shape[1] // 4
+    assert torch.equal(engine.op_fps(xyz.to(DEV), m).cpu().long(), P.furthest_sampling(xyz, m))
+
+
 def test_paconv_embedder_matches_reference_golden():
     """PAConv U-Net (320 -> 80 -> 20 -> 5 -> 1 points: n < nsample heap tails, single known point in FP) vs the golden produced
     by the reference's own Python with the pointops kernels substituted by their CPU restatements."""

@@ -185,3 +185,46 @@ def test_batchnorm_running_statistics_combine_as_one_population():
     var = (v[0] + m[0] ** 2 + v[1] + m[1] ** 2) / 2 - mean ** 2
     for _, rm, rv in res:
         assert torch.allclose(torch.from_numpy(rm), mean, atol=1e-6) and torch.allclose(torch.from_numpy(rv), var, atol=1e-6)
+
+
+def _mask_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, b, c = (torch.nn.Parameter(torch.ones(3) * (i + 1)) for i in range(3))
+        red = shard.GradientReducer([a, b, c], bucket_bytes=16)
+        seen = []
+        # step 1: c receives a gradient on rank 1 only; steps 2, 3: on no rank -- rank 0's OWN pattern (a, b) never changes
+        for step in range(3):
+            red.zero_grad()
+            loss = (a * a).sum() + (b * 2.0).sum()
+            if rank == 1 and step == 0:
+                loss = loss + (c * 3.0).sum()
+            loss.backward()
+            red.finish()
+            seen.append([p.grad is None for p in (a, b, c)])
+            if not seen[-1][2]:
+                assert torch.allclose(c.grad, torch.full((3,), 3.0))          # the SUM over ranks: 0 + 3
+        red.remove()
+        q.put((rank, seen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_gradient_presence_mask_follows_the_other_rank():
+    """A parameter that loses its gradient on the ONLY rank that had one must become `.grad = None` on every rank in that same step, also on
+    the ranks whose own presence pattern did not change (round-3 advisor finding: a cache keyed on the local pattern kept the stale list
+    there, and FlatAdam then updated the parameter on some replicas only)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mask_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=100) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, seen in res:
+        assert seen == [[False, False, False], [False, False, True], [False, False, True]], (rank, seen)
