@@ -114,6 +114,127 @@ def cpu_baseline(cfg, md, points, seed, sd=None):
                       f"{dt:.1f} s of host time"}, lp
 
 
+def kernel_peak(name):
+    """(limb products issued per fp32-equivalent product, peak TFLOP/s, note) of a matrix-core kernel by the name rocprofv3 prints for it.
+    SURVEY.md 8(d): achieved = ALGORITHMIC fp32-equivalent FLOPs of the launches / their time, against the dense 16-bit MFMA peak the loop runs
+    on; the split loops issue n limb products per fp32-equivalent product: that issue rate is frac_issued, never frac."""
+    var = next((v for v in SPLIT_MFMA_PER_PRODUCT if name.endswith(f", {v}>(fc::GemmParams)")), None)   # ..., VAR>
+    if var is None and any(k in name for k in ("attn16_kernel", "mlp_rows_kernel", "premlp_rows_kernel", "premlp_kernel", "spline_wide_kernel")):
+        var = 5                                             # split-fp16 attention / row-resident MLP chains / the one-accumulator 256 x 256 kernels: 3 limb products
+    if var is not None:
+        n = SPLIT_MFMA_PER_PRODUCT[var]
+        return n, PEAK_BF16_MATRIX_TFLOPS, (f"split-{'fp16' if var != 3 else 'bf16'} loop on the dense fp16/bf16 MFMA peak 2500 TFLOP/s: achieved = algorithmic fp32-equivalent "
+                                            f"multiply-add FLOPs (padding excluded); the loop issues {n} limb products per fp32-equivalent product, so the 16-bit MFMA FLOPs "
+                                            "actually issued are issued_tflops (frac_issued of the same peak); the fp32-input MFMA peak would be 157.3 TFLOP/s")
+    return 1, PEAK_F32_MATRIX_TFLOPS, "fp32-input MFMA (v_mfma_f32_32x32x2_f32) against its dense peak 157.3 TFLOP/s"
+
+
+def pmc_tables(workload_key):
+    """Committed counter passes of THIS workload (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE per launch, FETCH doubled per the gfx950
+    correction; profiles/pmc_mfma_busy.json: matrix-pipe busy fraction and clock), keyed by the kernel names rocprofv3 prints.  Counters cannot be
+    collected inside a timed run; a table measured on another workload does not apply.  Returns (traffic, busy, reason-or-None)."""
+    out = [{}, {}]
+    why = None
+    for i, f in enumerate(("pmc_traffic.json", "pmc_mfma_busy.json")):
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", f)))
+            meas = pj.get("measured", {})
+            if meas.get("workload", "c2_dgcnn_attn_spline 16 x 4096 + 4096") != workload_key:
+                why = f"the committed counter passes are of another workload ({meas.get('workload', 'c2_dgcnn_attn_spline 16 x 4096 + 4096')})"
+                continue
+            out[i] = {"kernels": pj["kernels"], "measured": meas}
+        except (OSError, KeyError, ValueError):
+            why = why or f"profiles/{f} missing"
+    return out[0], out[1], why
+
+
+def roofline_of(p, traffic, busy, why):
+    """One kernel's roofline entry from its in-library HIP-event record p = {kernel, launches, ms, flops, bytes}."""
+    per_launch_ms = p["ms"] / p["launches"]
+    if p["flops"] > 0:
+        useful = p["flops"] / p["launches"] / (per_launch_ms * 1e-3) / 1e12          # fp32-equivalent multiply-add TFLOP/s
+        n, peak, note = kernel_peak(p["kernel"])
+        r = {"bound": "mfma", "kernel": p["kernel"], "achieved": useful, "peak": peak, "unit": "TFLOP/s", "frac": useful / peak,
+             "frac_issued": useful * n / peak, "issued_tflops": useful * n, "peak_source": "MI355X_MICROARCH.md; " + note}
+    elif p["bytes"] > 0:
+        achieved = p["bytes"] / p["launches"] / (per_launch_ms * 1e-3) / 1e9
+        r = {"bound": "hbm", "kernel": p["kernel"], "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS}
+    else:
+        r = {"bound": None, "kernel": p["kernel"], "achieved": None, "peak": None, "unit": None, "frac": None}
+    t = traffic.get("kernels", {}).get(p["kernel"]) if traffic else None
+    r["traffic"] = t["hbm_bytes_per_launch"] if t else None
+    if t:
+        meas = traffic.get("measured", {})
+        r["traffic_unit"] = ("HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                             f"(profiles/pmc_traffic.json, measured {meas.get('date', '?')} on build {meas.get('label', '?')})")
+    else:
+        r["traffic_note"] = why or "no counter pass committed for this kernel"
+    b = busy.get("kernels", {}).get(p["kernel"]) if busy else None
+    if b:
+        r["matrix_pipe_busy"] = b.get("mfma_busy_frac")
+        r["clock_ghz"] = b.get("clock_ghz")
+    r["avg_launch_ms"] = per_launch_ms
+    r["launches"] = p["launches"]
+    return r
+
+
+def device_identity(dev):
+    """What tells two GPUs apart: UUID where torch exposes it, PCI address otherwise (both constant per device)."""
+    pr = torch.cuda.get_device_properties(dev)
+    uuid = str(getattr(pr, "uuid", ""))
+    pci = ":".join(str(getattr(pr, a, "?")) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return f"{uuid}|{pci}|{pr.name}"
+
+
+def training_child_command(args, steps):
+    """argv of the child that runs the training leg of THIS workload (bench.py --train-child: prints bench.py --train's JSON line)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--train-child", "--gpus", str(args.gpus), "--steps", str(steps), "--warmup", "1",
+           "--config", args.config, "--batch", str(args.batch), "--points", str(args.points), "--weights", args.weights]
+    if args.ctx_points:
+        cmd += ["--ctx-points", str(args.ctx_points)]
+    if args.layers:
+        cmd += ["--layers", str(args.layers)]
+    for kv in args.knob:
+        cmd += ["--knob", kv]
+    return cmd
+
+
+def training_child_env(environ):
+    """The child's rendezvous: same rank / world / address, the NEXT port (the parent's store may still hold its port)."""
+    env = dict(environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("RANK", "0")
+    env.setdefault("LOCAL_RANK", "0")
+    env.setdefault("WORLD_SIZE", "1")
+    return env
+
+
+def parse_training_child(rc, stdout, timed_out=False):
+    """The `train` object from a child's outcome: its JSON line's `train` field, or {"error": ...} (non-zero exit, no line, timeout)."""
+    if timed_out:
+        return {"error": "training leg (child process) exceeded its time limit and was killed"}
+    line = next((l for l in reversed(stdout.splitlines()) if l.startswith("{")), None)
+    if rc != 0 or line is None:
+        return {"error": f"training leg (child process) failed: exit code {rc}" + ("" if line else ", no JSON line")}
+    try:
+        j = json.loads(line)
+        return dict(j["train"], phase="second, guarded phase: child processes with their own RCCL process group")
+    except (ValueError, KeyError) as e:
+        return {"error": f"training leg (child process): unreadable line ({e})"}
+
+
+def run_training_child(args, rank, world, limit_s=900.0):
+    import subprocess
+    cmd, env = training_child_command(args, args.train_steps), training_child_env(os.environ)
+    log(f"rank {rank}: training leg in a child process (MASTER_PORT {env['MASTER_PORT']})")
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, timeout=limit_s)
+        return parse_training_child(r.returncode, r.stdout)
+    except subprocess.TimeoutExpired:
+        return parse_training_child(-1, "", timed_out=True)
+
+
 def fp16_fallbacks():
     import ctypes
     L = engine.lib()
@@ -128,6 +249,7 @@ def train_steps(args, cfg, md, batch, eps, dist, world, rank, dev, steps, warmup
     md["input_embedder"].train()
     params = [p for p in md["parameters"] if p.requires_grad]
     reducer = shard.GradientReducer(params)
+    reducer.time_exposed = True
     opt = shard.FlatAdam(reducer, lr=1e-5)                # clip_grad_norm_ + Adam as HIP kernels on the reducer's flat buffers
     B, N = batch[1].shape[0], batch[1].shape[1]
     n_global = world * B * N
@@ -140,6 +262,7 @@ def train_steps(args, cfg, md, batch, eps, dist, world, rank, dev, steps, warmup
             log(f"rank {rank}: training warmup step {i}: loss {float(loss):.4f} |grad| {float(norm):.3e} peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
         dist.barrier()
         torch.cuda.synchronize()
+        reducer.exposed_events = []
         t0 = time.perf_counter()
         for _ in range(steps):
             loss, lp, bpd, norm = shard.local_training_step(batch, n_global, md, cfg, reducer, optimizer=opt, eps=eps)
@@ -154,7 +277,9 @@ def train_steps(args, cfg, md, batch, eps, dist, world, rank, dev, steps, warmup
         md["flow"].eval()
         md["input_embedder"].eval()
     n_par = sum(p.numel() for p in reducer.params)
-    return {"ms_per_step": dt / steps * 1e3, "points_per_sec": n_global * steps / dt, "steps": steps, "warmup": warmup,
+    exposed = reducer.exposed_ms()
+    return {"all_reduce_exposed_ms_per_step": exposed,
+            "ms_per_step": dt / steps * 1e3, "points_per_sec": n_global * steps / dt, "steps": steps, "warmup": warmup,
             "loss": float(loss), "grad_norm": float(norm), "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2**30,
             "fp16_fallbacks": fp16_fallbacks() - fb0,
             "what": "forward + backward (HIP training kernels) + bucketed RCCL gradient all-reduce + clip_grad_norm_ + Adam, embedder in train() mode "
@@ -175,7 +300,7 @@ def train_main(args, cfg, md, batch, eps, dist, world, rank, dev):
             "config": {"workload": f"{args.config}: batch {B} scenes/GPU x {N} target + {N} context points, {cfg['n_flow_layers']} flow layers, embedder trained",
                        "global_batch": world * B, "points_per_scene": N,
                        "parallelism": f"scene-sharded x{world}; gradient all-reduce: {r['gradient_all_reduce']}"},
-            "loss": r["loss"], "grad_norm": r["grad_norm"], "peak_mem_GiB": r["peak_mem_GiB"]}), flush=True)
+            "loss": r["loss"], "grad_norm": r["grad_norm"], "peak_mem_GiB": r["peak_mem_GiB"], "train": r}), flush=True)
     dist.destroy_process_group()
 
 
@@ -186,7 +311,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2_dgcnn_attn_spline")
     ap.add_argument("--batch", type=int, default=16, help="scenes per GPU")
-    ap.add_argument("--points", type=int, default=4096, help="target points = context points per scene")
+    ap.add_argument("--points", type=int, default=4096, help="target points per scene (and context points, unless --ctx-points)")
+    ap.add_argument("--ctx-points", type=int, default=None,
+                    help="context points per scene when they differ from the target points: the reference's native training shape is 20 scenes x 1024 "
+                         "target x 1250 context points (config/dulcet-universe.yaml:1-3,44-46,185-187): --config c4_dgcnn_attn_extra_affine --batch 20 "
+                         "--points 1024 --ctx-points 1250")
+    ap.add_argument("--fixed-eps", action="store_true",
+                    help="diagnostic: draw the augmenter's noise once before the timed region (rounds 1-3).  Default: every step draws its own eps on the "
+                         "device inside the timed region, as the reference does in every forward (models/augmenter.py:49-63)")
+    ap.add_argument("--train-in-child", action="store_true", help="run the training leg as the guarded second phase also with one rank (what more than one rank always does)")
+    ap.add_argument("--train-child", action="store_true", help=argparse.SUPPRESS)      # (internal: the training leg of a multi-rank run, as a child process)
     ap.add_argument("--layers", type=int, default=None, help="override n_flow_layers (INVALID as a headline number)")
     ap.add_argument("--weights", choices=("conditioned", "module"), default="conditioned",
                     help="conditioned (default): module init + flowcompare_amd.conditioning.condition_flow (near-identity coupling output layers, "
@@ -217,7 +351,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.train_steps is None:
-        args.train_steps = 2 if world == 1 else 0
+        args.train_steps = 2                              # (with more than one rank the leg runs as a second, guarded phase in child processes: below)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -236,6 +370,12 @@ def main():
         sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
         init_rccl(dist, dev, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
 
+    census = None
+    if dist is not None:
+        census = shard.device_census(device_identity(dev))
+        if census["unique_devices"] != world:
+            log(f"rank {rank}: WARNING {world} ranks on {census['unique_devices']} distinct devices")
+
     over = {"sample_size": args.points}
     if args.layers:
         over["n_flow_layers"] = args.layers
@@ -245,25 +385,29 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):          # the reference API prints its parameter count: stdout carries only the JSON line
         md = fa.initialize_flow(cfg, device=dev, mode="test")
     B, N = args.batch, args.points
+    M = args.ctx_points or N
     if args.weights == "conditioned":
         # the same two conditioning scenes on every rank -> identical weights on every rank (kernel work does not depend on the values)
         from flowcompare_amd.conditioning import condition_flow
-        c0, c1, cx, cg = synth_pairs(2, N, N, 999, dev)
+        c0, c1, cx, cg = synth_pairs(2, M, N, 999, dev)
         ceps = [torch.randn(2, N, cfg["latent_dim"] - cfg["input_dim"], generator=cg).to(dev)]
         t_c = time.perf_counter()
         condition_flow(md, cfg, (c0, c1, cx if cfg["extra_z_value_context"] else None), eps=ceps)
         torch.cuda.synchronize()
         log(f"rank {rank}: weights conditioned in {time.perf_counter() - t_c:.1f} s")
         del c0, c1, cx, ceps
-    e0, e1, extra, g = synth_pairs(B, N, N, 1000 + rank, dev)   # every rank owns different scenes
+    e0, e1, extra, g = synth_pairs(B, M, N, 1000 + rank, dev)   # every rank owns different scenes
     batch = (e0, e1, extra if cfg["extra_z_value_context"] else None)
     eps = [torch.randn(B, N, cfg["latent_dim"] - cfg["input_dim"], generator=g).to(dev)]
+    torch.cuda.manual_seed(4000 + rank)
 
-    if args.train:
+    if args.train or args.train_child:
         return train_main(args, cfg, md, batch, eps, dist, world, rank, dev)
 
     def step():
-        loss, lp, bpd = fa.inner_loop(batch, md, cfg, eps=eps)
+        # the augmenter's noise is part of a forward (models/augmenter.py:49-63: drawn in every call): one device randn of B x N x 294 per step
+        e = eps if args.fixed_eps else [torch.randn(B, N, cfg["latent_dim"] - cfg["input_dim"], device=dev)]
+        loss, lp, bpd = fa.inner_loop(batch, md, cfg, eps=e)
         if dist is not None:                              # global mean over all ranks' scenes: the only exchange of the path
             loss, bpd = shard.global_loss_bpd(lp, cfg["input_dim"])
         return loss, lp, bpd
@@ -342,47 +486,11 @@ def main():
         breakdown, bsteps = (warm_prof, 1) if warm_prof else (prof, args.steps)      # all kernels: last warmup step
         breakdown.sort(key=lambda p: -p["ms"])
         tot_ms = sum(p["ms"] for p in breakdown) / bsteps * args.steps or 1.0
-        per_launch_ms = dom["ms"] / dom["launches"]
-        if dom["flops"] > 0:
-            useful = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12          # fp32-equivalent multiply-add TFLOP/s
-            var = next((v for v in SPLIT_MFMA_PER_PRODUCT if dom["kernel"].endswith(f", {v}>(fc::GemmParams)")), None)   # ..., VAR>
-            if var is None and any(k in dom["kernel"] for k in ("attn16_kernel", "mlp_rows_kernel", "premlp_rows_kernel", "premlp_kernel", "spline_wide_kernel")):
-                var = 5                                     # split-fp16 attention / row-resident MLP chains: 3 limb products per fp32-equivalent product
-            # achieved = ALGORITHMIC fp32-equivalent FLOPs of the launches / their time, against the dense 16-bit MFMA peak the
-            # loop runs on.  The split loops issue n limb products per fp32-equivalent product: that issue rate is reported beside it as
-            # frac_issued (what the matrix pipes are asked to do), never as frac.
-            if var is not None:
-                n = SPLIT_MFMA_PER_PRODUCT[var]
-                peak = PEAK_BF16_MATRIX_TFLOPS
-                note = (f"split-{'fp16' if var != 3 else 'bf16'} loop on the dense fp16/bf16 MFMA peak 2500 TFLOP/s: achieved = algorithmic fp32-equivalent "
-                        f"multiply-add FLOPs (padding excluded); the loop issues {n} limb products per fp32-equivalent product, so the 16-bit MFMA FLOPs "
-                        "actually issued are issued_tflops (frac_issued of the same peak); the fp32-input MFMA peak would be 157.3 TFLOP/s")
-            else:
-                n = 1
-                peak = PEAK_F32_MATRIX_TFLOPS
-                note = "fp32-input MFMA (v_mfma_f32_32x32x2_f32) against its dense peak 157.3 TFLOP/s"
-            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": useful, "peak": peak, "unit": "TFLOP/s",
-                    "frac": useful / peak, "frac_issued": useful * n / peak, "issued_tflops": useful * n, "traffic": None,
-                    "frac_note": "frac = algorithmic fp32-equivalent FLOPs (SURVEY.md 8d) / peak; frac_issued = MFMA FLOPs issued / the same peak (issue rate)",
-                    "peak_source": "MI355X_MICROARCH.md; " + note}
-        else:
-            achieved = dom["bytes"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": achieved / PEAK_HBM_GBS, "traffic": None}
-        # HBM bytes per launch of that kernel from the committed PMC passes of this same command (profiles/pmc_summary.py: separate
-        # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction); PMC cannot be collected inside a timed run
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            pmc = pj["kernels"].get(dom["kernel"])
-            if pmc and args.config == "c2_dgcnn_attn_spline" and B == 16 and N == 4096 and not args.layers:
-                roof["traffic"] = pmc["hbm_bytes_per_launch"]
-                meas = pj.get("measured", {})
-                roof["traffic_unit"] = ("HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                        f"(profiles/pmc_traffic.json, measured {meas.get('date', '?')} on build {meas.get('label', '?')}; counters cannot be "
-                                        "collected inside a timed run)")
-        except (OSError, KeyError, ValueError):
-            pass
-        roof.update({"avg_launch_ms": per_launch_ms, "launches": dom["launches"], "launches_bracketed": f"every {stride}th launch of this kernel in the timed region" if stride > 1 else "all",
+        workload_key = f"{args.config} {B} x {N} + {M}" + (f" ({args.layers} layers)" if args.layers else "")
+        traffic, busy, why = pmc_tables(workload_key)
+        roof = roofline_of(dom, traffic, busy, why)
+        roof.update({"frac_note": "frac = algorithmic fp32-equivalent FLOPs (SURVEY.md 8d) / peak; frac_issued = MFMA FLOPs issued / the same peak (issue rate)",
+                     "launches_bracketed": f"every {stride}th launch of this kernel in the timed region" if stride > 1 else "all",
                      "share_of_gpu_time": dom_warm["ms"] / sum(p["ms"] for p in warm_prof) if warm_prof else dom["ms"] / tot_ms,
                      "flops_counted": "useful multiply-adds of the launches (padding excluded), HIP events on the launch stream"})
         alg = ALG_MFLOP_PER_POINT.get((args.config, N))
@@ -390,22 +498,46 @@ def main():
             "metric": "nats/sec (forward log-prob) on 4096-pt coloured pairs", "value": value, "unit": "nats/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16x2 split (fp32-equivalent operands, f32 accumulate) / f32", "data": "synthetic" + (" (conditioned random-init weights, flowcompare_amd/conditioning.py)" if args.weights == "conditioned" else " (module-init weights)"),
-            "config": {"workload": f"{args.config}: batch {B} scenes/GPU x {N} target + {N} context points, "
+            "config": {"workload": f"{args.config}: batch {B} scenes/GPU x {N} target + {M} context points, "
                                    f"{cfg['n_flow_layers']} flow layers ({cfg['flow_type']}), embedder {cfg['input_embedder']}",
-                       "global_batch": world * B, "points_per_scene": N, "parallelism": f"scene-sharded x{world}, no data-path collective"},
+                       "global_batch": world * B, "points_per_scene": N, "context_points_per_scene": M, "parallelism": f"scene-sharded x{world}, no data-path collective"},
             "mean_nats": mean_nats, "bpd": bpd_f, "weights": args.weights, "fp16_fallbacks": fallbacks,
+            "eps": "drawn once before the timed region (--fixed-eps)" if args.fixed_eps else "one device randn per step inside the timed region (models/augmenter.py:49-63)",
             "range_check": "per call (stream synchronisation)" if args.sync_range_check else "deferred: flags of the K queued forwards read at the end of the timed region (fc_range_check_defer)",
             "job_algorithmic_tflops": None if alg is None or args.layers else alg * 1e6 * value / 1e12,
+            "rccl": None if census is None else dict(census, backend="nccl (RCCL)", note="all_gather of every rank's device UUID / PCI address"),
             "roofline": roof,
             "kernels_source": "HIP events around every launch of the last warmup step" if warm_prof else "timed region",
-            "kernels": [{"kernel": p["kernel"], "launches": p["launches"], "ms_per_step": p["ms"] / bsteps,
-                         "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] else None,
-                         "gbs": (p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["bytes"] else None} for p in breakdown[:8]],
+            # every kernel of a step with its own roofline entry (frac / frac_issued / traffic / matrix-pipe busy where a counter pass of this workload is committed)
+            "kernels": [dict(roofline_of(p, traffic, busy, why), ms_per_step=p["ms"] / bsteps, launches=p["launches"],
+                             tflops=(p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] else None,
+                             gbs=(p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["bytes"] else None) for p in breakdown[:10]],
         }
 
     # `train` object: the training step of the same workload on the same clock (`bench.py --train` prints it as its own
-    # line).  Every rank takes part; the forward line is complete before it starts and is printed even if the leg fails or hangs.
-    if args.train_steps > 0 and not args.no_profile:
+    # line).  Every rank takes part; the forward numbers are complete before it starts and are printed even if the leg fails or hangs.
+    #   one rank: in this process, behind a watchdog;
+    #   more than one rank (or --train-in-child): a SECOND, GUARDED PHASE -- the multi-rank RCCL gradient exchange runs in fresh child processes
+    #   (one per rank, their own process group on MASTER_PORT + 1), after this process has released its device memory and left its process
+    #   group: a crash, an abort inside RCCL or a hang there cannot take the forward line with it, and the line then carries train.error and
+    #   the run exits non-zero.  (A child is started with subprocess; nothing is exec'ed from a process that has touched the GPU.)
+    exit_code = 0
+    if args.train_steps > 0 and not args.no_profile and (world > 1 or args.train_in_child):
+        del step
+        md = batch = eps = e0 = e1 = extra = lp = loss = bpd = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+            dist = None
+        train_obj = run_training_child(args, rank, world)
+        if "error" in train_obj:
+            exit_code = 5
+        if out is not None:
+            out["train"] = train_obj
+    elif args.train_steps > 0 and not args.no_profile:
         import threading
         done = threading.Event()
 
@@ -423,6 +555,7 @@ def main():
         except Exception as e:                            # noqa: BLE001 -- reported in the line, the forward numbers stand
             train_obj = {"error": f"{type(e).__name__}: {e}"[:300]}
             log(f"rank {rank}: training leg failed: {e}")
+            exit_code = 5
         done.set()
         if out is not None:
             out["train"] = train_obj
@@ -434,6 +567,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

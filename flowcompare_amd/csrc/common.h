@@ -110,6 +110,8 @@ struct PackedLinear {
                                    // [round_up(N_pad, 256)][K_pad/16][2][16]: w 2^w1_exp = hi + lo with lo UNSCALED, rows in that kernel's column order
     float* bias1 = nullptr;        // its bias in the same order, times kOneAccActScale 2^w1_exp
     int w1_exp = 0;
+    bool w1_permuted = false;      // W1 rows in the fused spline kernel's register-slot order (else natural order: a Linear layer of the coupling MLP)
+    float wmax = 0.f;              // max |w| of the packed matrix (pack_linear)
     int N_pad = 0;             // columns written (multiple of 32)
     int K_pad = 0;             // multiple of 32 (sum of segment widths)
     int seg_k[3] = {0, 0, 0};  // padded K of each A segment
@@ -149,7 +151,8 @@ struct GemmEpi {
                                               // following split-fp16 GEMM, which then copies it instead of re-splitting it per column tile)
     const unsigned short* A16 = nullptr;      // input: the A operand given as such an image (single segment of K_pad columns)
     float c16_scale = 0.f;                    // C16 in the one-accumulator form instead: hi + lo of value * c16_scale, lo unscaled (0: the hi + lo'/2048 form)
-    float a16_scale = 0.f;                    // A16 arrives in that form (EPI_SPLINE on spline_wide.hip only)
+    float a16_scale = 0.f;                    // A16 arrives in that form (spline_wide.hip: the fused spline layer and the 512-wide Linear layers)
+    float r16_scale = 0.f;                    // residual16 arrives in that form
     // EPI_AFFINE (W pair-packed [s 32 | t 32] x pairs): in-place y2 = x2*s + t on xbuf, logprob[row] += sum log s
     // EPI_AUGMENT (W pair-packed [mu 32 | logsigma 32]): z2 = mu + eps*sigma scattered into xbuf, logprob += -log N(z2)
     float* xbuf = nullptr; int ldx = 0;
@@ -283,8 +286,12 @@ void launch_mlp_rows(const PackedLinear& in, const std::vector<PackedLinear>& mi
 void launch_limb_decode(const unsigned short* img, float* out, int ldo, int rows, int width, hipStream_t s);   // row-major limb image -> fp32 (tests)
 // spline_wide.hip: the fused spline parameter layer on 256 x 256 tiles with one accumulator per output (K = 8 bins, limb-chained input)
 bool spline_wide_eligible(const PackedLinear& L, int K_bins);
-void spline_wide_attach(DeviceArena& arena, PackedLinear& L, float wmax, hipStream_t s);
+void spline_wide_attach(DeviceArena& arena, PackedLinear& L, float wmax, hipStream_t s, bool permute = true);
 void launch_spline_wide(const PackedLinear& L, const GemmEpi& e, int rows_alloc, hipStream_t s);
+bool linear_wide_eligible(const PackedLinear& L, const GemmEpi& e, int rows_alloc);   // a GELU Linear layer with one-accumulator images in and out
+void launch_linear_wide(const PackedLinear& L, const GemmEpi& e, int rows_alloc, hipStream_t s);
+bool gemm_linear_wide_on();      // knob 29 (1: for scenes of at least 2048 target points, 2: at any size)
+int gemm_linear_wide_knob();
 bool gemm_spline_wide_on();      // knob 13 = 5 (shipped): launch_gemm routes eligible EPI_SPLINE launches there
 // staging.hip: the steps either side of the path
 void launch_fps_nd(const float* pts, int ld, int C, int64_t* idx, int B, int n, int m, float* dist_scratch, hipStream_t s);

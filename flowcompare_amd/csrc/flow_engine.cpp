@@ -576,7 +576,16 @@ void flow_set_trace(float* buf, size_t floats) { t_flow_trace = buf; t_flow_trac
 int g_premlp_chain = 0;      // knob 19: limb chain through the pre-attention MLP into the LayerNorm -> q GEMM (K = 256: 8 k-tiles per
                              // output tile, the tile-boundary cost of the DMA loop outweighs its main loop: measured 1 % slower end to end)
 static int run_mlp_hidden(const fc_flow& f, const PackedMLP& m, const ASeg* in_segs, const float* rowscal, FlowWs& w, int act, hipStream_t s,
-                          unsigned short* last_limbs = nullptr, float last_scale = 0.f) {
+                          unsigned short* last_limbs = nullptr, float last_scale = 0.f, int n_scene = 0) {
+    // round 4: hidden layers of a 512-wide coupling net on the 256 x 256 one-accumulator kernel (spline_wide.hip EPI 1).  The gate is the SCENE's
+    // size (target points per scene), never the batch's: a scene's log-probs must not depend on the batch it sits in, and this arithmetic
+    // (one accumulator, k32 MFMAs) is not the per-layer 128 x 128 / 64 x 64 loops' or the row-resident chain's.
+    const int wk = gemm_linear_wide_knob();
+    if (last_limbs && f.d.H_pad == 512 && gemm_limb_chain_all_ok() && act == FC_ACT_GELU && (wk == 2 || (wk == 1 && n_scene >= 2048)) && w.P_pad % 256 == 0 && !m.mid.empty()) {
+        bool ok = true;
+        for (const PackedLinear& L : m.mid) ok = ok && L.W1 && !L.w1_permuted && L.N_pad % 256 == 0 && L.K_pad % 64 == 0;
+        if (ok) return run_mlp_hidden_generic(m, in_segs, rowscal, act, w.h, std::max(f.d.H_pad, 32), w.P_pad, s, w.P, last_limbs, last_scale, true);
+    }
     // 512-wide coupling nets inside a guard scope: in_layer + hidden layers as ONE row-resident launch (mlprows.hip); the scratch images
     // of its intermediate activations live in the h[] buffers (same 2 KB per row as a 512-wide fp32 panel)
     // (a workgroup owns 128 rows for the whole chain: with fewer workgroups than ~3/4 of the CUs -- C1's 2 x 1024 points are 16 -- the chain
@@ -683,7 +692,7 @@ static void run_coupling(fc_flow& f, const BlockPack& b, FlowWs& w, float* xc, c
                            b.net.out_layer.nseg == 1 && !b.net.mid.empty();
     // round 4: the chain's last activation in the one-accumulator form (common.h kOneAccActScale) for the 256 x 256 fused spline kernel (spline_wide.hip)
     const bool wide = chain && gemm_spline_wide_on() && spline_wide_eligible(b.net.out_layer, c.num_bins_spline) && w.P_pad % 256 == 0;
-    const int cur = run_mlp_hidden(f, b.net, segs, rowscal, w, c.nonlinearity, s, (chain || chain_aff) ? w.h16 : nullptr, wide ? kOneAccActScale : 0.f);
+    const int cur = run_mlp_hidden(f, b.net, segs, rowscal, w, c.nonlinearity, s, (chain || chain_aff) ? w.h16 : nullptr, wide ? kOneAccActScale : 0.f, N);
     ASeg a{(chain || chain_aff) ? w.h[0] : w.h[cur], ldh};
     if (c.flow_type == FC_FLOW_AFFINE) {
         GemmEpi e{};
@@ -746,6 +755,10 @@ static Prep prepare(fc_flow& f, const float* ctx, const float* extra, int B, int
     p.w = plan_ws(f, B, N, M, ws, ws_bytes, false, nullptr);
     FlowWs& w = p.w;
     launch_pack_rows(ctx, d.E, d.E, w.ctxp, d.E_pad, 0, d.E_pad, w.Pc, s);
+    // pad rows of the context panel: the K|V projection stages them like any row, and stale workspace bytes there (a NaN, a value beyond fp16's
+    // range) would raise the split-fp16 range flag -- a needless repeat of the whole pass on the bf16 limbs, and a scene whose log-probs then
+    // depend on what ran in the workspace before (found in round 4: one scene of 200 context points behind a three-scene batch)
+    if (w.Pc_pad > w.Pc) launch_fill(w.ctxp + (size_t)w.Pc * d.E_pad, 0.f, (size_t)(w.Pc_pad - w.Pc) * d.E_pad, s);
     if (d.X) { launch_repeat_extra(extra, d.X, w.rowscal, B, N, s); p.rowscal = w.rowscal; }
     if (f.n_attn) {
         // inside a guard scope the stacked K|V projection writes its output straight as the limb image the split-fp16 attention
@@ -787,6 +800,7 @@ static void flow_forward(fc_flow& f, const float* x, const float* ctx, const flo
     launch_fill(xc, 0.f, (size_t)w.P_pad * d.ldx, s);
     if (f.has_augment) {
         launch_pack_rows(x, d.Din, d.Din, w.xin, 32, 0, 32, w.P, s);
+        if (w.P_pad > w.P) launch_fill(w.xin + (size_t)w.P * 32, 0.f, (size_t)(w.P_pad - w.P) * 32, s);      // (pad rows: zeros, not stale workspace bytes)
         const int n1 = std::min(d.Din, d.d1);                                       // latent[0:Din] = x, split over the x1 | x2 regions
         launch_pack_rows(x, d.Din, n1, xc, d.ldx, 0, n1, w.P, s);
         if (d.Din > n1) launch_pack_rows(x + n1, d.Din, d.Din - n1, xc, d.ldx, d.d1_pad, d.Din - n1, w.P, s);

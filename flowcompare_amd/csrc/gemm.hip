@@ -22,6 +22,7 @@
 #include <atomic>
 #include <type_traits>
 #include <cstdio>
+#include <cstdlib>
 
 namespace fc {
 
@@ -1425,7 +1426,19 @@ static void launch_cfg(const GemmParams& p, hipStream_t s) {
 bool gemm_dev_variants() { return kDevVariants; }
 bool gemm_spline_wide_on() { return g_gemm_dma == 5 && g_gemm_variant == 5 && g_gemm_bigtile == 3 && g_fused_spline && g_limb_chain && g_spline_ablate != 3 && g_spline_ablate != 4 && g_spline_ablate != 5; }
 
+static void launch_gemm_impl(const PackedLinear& L, const ASeg* segs, int rows_alloc, const GemmEpi& e_in, int epi_kind, hipStream_t s);
 void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const GemmEpi& e_in, int epi_kind, hipStream_t s) {
+    static const bool trace = getenv("FC_FLAG_TRACE") != nullptr;      // diagnostic: which launch raises the split-fp16 range flag
+    int before = 0, after = 0;
+    if (trace && t_fp16_flag) { FC_HIP(hipStreamSynchronize(s)); FC_HIP(hipMemcpy(&before, t_fp16_flag, 4, hipMemcpyDeviceToHost)); }
+    launch_gemm_impl(L, segs, rows_alloc, e_in, epi_kind, s);
+    if (trace && t_fp16_flag) {
+        FC_HIP(hipStreamSynchronize(s)); FC_HIP(hipMemcpy(&after, t_fp16_flag, 4, hipMemcpyDeviceToHost));
+        if (after != before) fprintf(stderr, "[flag trace] launch_gemm epi %d rows %d N %d K %d c16 %d (scale %g) a16 %d: flag %d -> %d\n", epi_kind, rows_alloc, L.N_pad, L.K_pad, e_in.C16 != nullptr,
+                                     e_in.c16_scale, e_in.A16 != nullptr, before, after);
+    }
+}
+static void launch_gemm_impl(const PackedLinear& L, const ASeg* segs, int rows_alloc, const GemmEpi& e_in, int epi_kind, hipStream_t s) {
     if (rows_alloc % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "launch_gemm: rows must be padded to ROW_PAD");
     const int v_bigtile = kDevVariants ? g_gemm_bigtile : 3;
     const int v_dma_linear = kDevVariants ? g_gemm_dma_linear : 2;
@@ -1464,7 +1477,12 @@ void launch_gemm(const PackedLinear& L, const ASeg* segs, int rows_alloc, const 
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: the training epilogues (Cpre / gradu) exist on VAR 2 / 3 / 5 only; this developer variant would ignore them");
         if (e.C16 && !(f16 && v_bigtile == 3 && L.N_pad > 64 && L.N_pad % 16 == 0))
             throw Error(FC_ERR_UNSUPPORTED, "launch_gemm: limb-image output exists on the eight-wave split-fp16 tile only");
-        if (e.a16_scale != 0.f) throw Error(FC_ERR_INVALID, "launch_gemm: a one-accumulator activation image is an input of the fused spline layer only");
+        if (e.a16_scale != 0.f) {                                       // a one-accumulator activation image: the 256 x 256 Linear kernel (spline_wide.hip EPI 1) only
+            if (!(f16 && linear_wide_eligible(L, e, rows_alloc))) throw Error(FC_ERR_INVALID, "launch_gemm: a one-accumulator activation image needs the wide Linear kernel (GELU layer, images in and out, N % 256 == 0)");
+            launch_linear_wide(L, e, rows_alloc, s);
+            return;
+        }
+        if (e.r16_scale != 0.f) throw Error(FC_ERR_INVALID, "launch_gemm: a one-accumulator residual image goes with a one-accumulator A image");
         if (e.A16) {
             p.e.inverse = g_spline_ablate;
             // A arrives as the limb image of the producing layer (limb-chained MLP): the copy-only main loops

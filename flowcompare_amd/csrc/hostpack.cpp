@@ -348,6 +348,7 @@ PackedLinear pack_linear(DeviceArena& arena, const MatD& W, const VecD& bias, co
     }
     for (int n : nmap) L.n_true += n >= 0;
     for (int k : kmap) L.k_true += k >= 0;
+    for (float x : w) L.wmax = std::max(L.wmax, std::fabs(x));
     L.W = arena.upload(w);
     L.bias = arena.upload(b);
     if (g_pack_bf16_limbs && L.K_pad % 16 == 0) {
@@ -388,17 +389,22 @@ void pack_mlp_mid(DeviceArena& arena, const WeightTable& wt, const std::string& 
     if (w_out.shape.size() != 2 || w_out.shape[1] != out.sizes.back()) throw Error(FC_ERR_SHAPE, prefix + ".out_layer.weight: input width mismatch");
 }
 int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float* rowscal, int act, float* const h[3], int ldh, int rows,
-                           hipStream_t s, int rows_valid, unsigned short* last_limbs, float last_scale) {
+                           hipStream_t s, int rows_valid, unsigned short* last_limbs, float last_scale, bool wide) {
     // Full limb chain (with `last_limbs`, inside a guard scope, every layer with an fp16 image and 128-multiple widths): EVERY hidden
     // activation exists only as the fp16 limb image its producer's epilogue writes (same 4 bytes per element as fp32, in the h[] buffers);
     // the consumers copy it (A16: no conversion in the main loop, LDS-DMA) and the odd layers read their residual from the image too.
     bool all = last_limbs && gemm_limb_chain_all_ok() && m.in_layer.W2 && m.in_layer.N_pad % 128 == 0 && m.in_layer.N_pad <= ldh;
+    // wide: the hidden layers on the 256 x 256 one-accumulator kernel (spline_wide.hip), every intermediate image in the one-accumulator form
+    bool wide_ok = wide && act == FC_ACT_GELU && rows % 256 == 0 && !m.mid.empty();
+    for (const PackedLinear& L : m.mid) wide_ok = wide_ok && L.W1 && !L.w1_permuted && L.N_pad % 256 == 0 && L.K_pad % 64 == 0;
     int prev_n = m.in_layer.N_pad;
     for (const PackedLinear& L : m.mid) { all = all && L.W2 && L.nseg == 1 && L.N_pad % 128 == 0 && L.K_pad == prev_n && L.N_pad <= ldh; prev_n = L.N_pad; }
     GemmEpi e{};
     e.act = act; e.C = h[0]; e.ldc = ldh; e.rowscal = rowscal; e.rows_valid = rows_valid;
     if (last_limbs && m.mid.empty()) { e.C = nullptr; e.C16 = last_limbs; e.c16_scale = last_scale; }
     else if (all) { e.C = nullptr; e.C16 = reinterpret_cast<unsigned short*>(h[0]); }
+    wide_ok = wide_ok && all;
+    if (wide_ok) e.c16_scale = kOneAccActScale;
     launch_gemm(m.in_layer, in_segs, rows, e, EPI_LINEAR, s);
     int cur = 0, keep = -1;
     for (size_t i = 0; i < m.mid.size(); ++i) {
@@ -414,6 +420,11 @@ int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float*
             g.C = nullptr;
             g.C16 = last ? last_limbs : reinterpret_cast<unsigned short*>(h[nxt]);
             if (last) g.c16_scale = last_scale;
+            if (wide_ok) {
+                g.a16_scale = kOneAccActScale;
+                if (g.residual16) g.r16_scale = kOneAccActScale;
+                if (!last) g.c16_scale = kOneAccActScale;
+            }
         } else {
             if (i % 2 == 1) { g.residual = h[keep]; g.ldr = ldh; }
             if (last_limbs && last) { g.C = nullptr; g.C16 = last_limbs; g.c16_scale = last_scale; }
@@ -434,6 +445,8 @@ void attach_mlp_rows_images(DeviceArena& arena, PackedMLP& m) {
     };
     attach(m.in_layer);
     for (PackedLinear& L : m.mid) attach(L);
+    // round 4: the hidden layers' one-accumulator weight images for the 256 x 256 Linear kernel (spline_wide.hip EPI 1), natural row order
+    for (PackedLinear& L : m.mid) spline_wide_attach(arena, L, L.wmax, nullptr, false);
 }
 int max_hidden_pad(const PackedMLP& m) {
     int mx = 0;

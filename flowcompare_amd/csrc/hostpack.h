@@ -57,6 +57,6 @@ void attach_mlp_rows_images(DeviceArena& arena, PackedMLP& m);
 // last hidden activation (the caller applies out_layer with the epilogue it needs).  With `last_limbs` the LAST hidden layer writes its
 // output only as an fp16 limb image (GemmEpi::C16, pitch = its N_pad) and -1 is returned.
 int run_mlp_hidden_generic(const PackedMLP& m, const ASeg* in_segs, const float* rowscal, int act, float* const h[3], int ldh, int rows,
-                           hipStream_t s, int rows_valid = 0, unsigned short* last_limbs = nullptr, float last_scale = 0.f);   // last_scale: GemmEpi::c16_scale of that image
+                           hipStream_t s, int rows_valid = 0, unsigned short* last_limbs = nullptr, float last_scale = 0.f, bool wide = false);   // last_scale: GemmEpi::c16_scale of that image
 
 }  // namespace fc

@@ -561,7 +561,7 @@ static void mr_launch(const MlpRowsParams& p, int rows_alloc, double flops, hipS
     static PerDeviceOnce attr_once;
     attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, MR_LDS)); return 0; });
     char name[96];
-    snprintf(name, sizeof name, "void fc::mlp_rows_kernel<%d, %d>(fc::MlpRowsParams)", KS0, ACT);
+    snprintf(name, sizeof name, "void fc::mlp_rows_kernel<%d, %d, %s>(fc::MlpRowsParams)", KS0, ACT, STAMPS ? "true" : "false");      // (the name rocprofv3 prints)
     ProfScope ps(name, flops, 0.0, s);
     hipLaunchKernelGGL(kern, dim3(rows_alloc / 128), dim3(256), MR_LDS, s, p);
     FC_HIP(hipGetLastError());

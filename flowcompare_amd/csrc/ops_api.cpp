@@ -17,7 +17,7 @@ struct TmpBuf {
 }  // namespace fc
 
 
-namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
+namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; extern int g_spline_wide_dma; extern int g_spline_wide_colgroup; extern int g_linear_wide; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }
 
 extern "C" {
@@ -25,7 +25,7 @@ extern "C" {
 /* tuning knobs for profiles/kernel_bench.py (not part of the stable ABI surface in fcflow.h on purpose) */
 int fc_debug_set(int32_t key, int32_t value) {
     if (!fc::kDevVariants && ((key == 0 && (value == 0 || value == 1)) || (key == 3 && value != 3) || (key == 8 && value == 1) || (key == 13 && value != 5 && value != 4 && value != 2) ||
-                              (key == 15 && value != 2) || (key == 17 && value != 0)))
+                              (key == 15 && value != 2) || (key == 17 && value != 0) || (key == 27 && value != 0)))
         return FC_ERR_UNSUPPORTED;       /* a developer variant: compiled only with -DFC_DEV_VARIANTS (python -m flowcompare_amd.build --dev) */
     if (key == 0) fc::g_gemm_variant = value;
     else if (key == 2) fc::g_gemm_colgroup = value;
@@ -47,6 +47,9 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 23) fc::g_mlp_rows = value;          /* 1 = row-resident coupling MLP chain (mlprows.hip, default), 0 = one GEMM launch per layer */
     else if (key == 26) fc::g_premlp_lu = value;         /* 1 = ActNorm + LU as a pre-layer of the row-resident pre-attention kernel (default), 0 = its own GEMM launch */
     else if (key == 24) fc::g_knn_mfma = value;          /* 1 = k-NN Gram tiles on the matrix cores (default), 0 = lane-per-candidate kernel */
+    else if (key == 27) fc::g_spline_wide_dma = value;   /* developer builds: DMA pieces per phase of the wide fused spline kernel (spline_wide.hip) */
+    else if (key == 29) fc::g_linear_wide = value;       /* hidden layers of the coupling MLP on the 256 x 256 one-accumulator kernel: 0 = off (default: measured no faster than the chain), 1 = for scenes of >= 2048 target points, 2 = at any size */
+    else if (key == 28) fc::g_spline_wide_colgroup = value;   /* column-group size of its tile order (-1 = shipped) */
     else if (key == 20) fc::g_gemm_stamp = value;        /* diagnostic: in-kernel phase stamps of the LDS-DMA fused-spline launches */
     else if (key == 14) fc::g_spline_ablate = value;     /* diagnostic: 1 = fused spline epilogue without the spline evaluation, 2 = main loop only (results invalid) */
     else return FC_ERR_INVALID;
@@ -181,8 +184,8 @@ int fc_op_mlp_hidden_f32(const float* x0, int32_t k0, const float* x1, int32_t k
     const float* rsp = rowscal && m.in_layer.colvec ? rs.f() : nullptr;
     FC_HIP(hipDeviceSynchronize());                       // (the images were built on the null stream)
     run_fp16_guarded((int*)flag.p, s, [&] {
-        if (use_rows) launch_mlp_rows(m.in_layer, m.mid, segs, rsp, act, h, (unsigned short*)h16.p, rp, rows, s);
-        else if (run_mlp_hidden_generic(m, segs, rsp, act, h, 512, rp, s, rows, (unsigned short*)h16.p) != -1)
+        if (use_rows == 1) launch_mlp_rows(m.in_layer, m.mid, segs, rsp, act, h, (unsigned short*)h16.p, rp, rows, s);
+        else if (run_mlp_hidden_generic(m, segs, rsp, act, h, 512, rp, s, rows, (unsigned short*)h16.p, 0.f, use_rows == 2) != -1)      // (2: hidden layers on the 256 x 256 one-accumulator kernel)
             throw Error(FC_ERR_INVALID, "fc_op_mlp_hidden_f32: the limb chain is off");
     });
     launch_limb_decode((const unsigned short*)h16.p, out, 512, rows, 512, s);

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include <cstdio>
 #include "activations.h"
 
 namespace fc {
@@ -686,25 +687,27 @@ void launch_premlp(const float* x, int ldx, const PackedLinear& in, const std::v
             auto kern = premlp_rows_kernel<FC_ACT_GELU, 5, 10>;
             static PerDeviceOnce attr_once;
             attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pr_lds(10))); return 0; });
-            ProfScope ps("fc::premlp_rows_kernel<lu>(fc::PreMlpParams)", flops, 0.0, s);
+            ProfScope ps("void fc::premlp_rows_kernel<1, 5, 10>(fc::PreMlpParams)", flops, 0.0, s);      // (the name rocprofv3 prints: profiles/pmc_traffic.json is keyed by it)
             hipLaunchKernelGGL(kern, dim3(rows_alloc / PR_ROWS), dim3(PR_NT), pr_lds(10), s, p);
             FC_HIP(hipGetLastError());
             return;
         }
-        auto go = [&](auto kern) {
+        auto go = [&](auto kern, int act_code, int ksin) {
             static PerDeviceOnce attr_once;                             // (one per kernel instantiation: `go` is a generic lambda)
             attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PR_LDS)); return 0; });
-            ProfScope ps("fc::premlp_rows_kernel(fc::PreMlpParams)", flops, 0.0, s);
+            char name[96];
+            snprintf(name, sizeof name, "void fc::premlp_rows_kernel<%d, %d, 0>(fc::PreMlpParams)", act_code, ksin);      // (the name rocprofv3 prints)
+            ProfScope ps(name, flops, 0.0, s);
             hipLaunchKernelGGL(kern, dim3(rows_alloc / PR_ROWS), dim3(PR_NT), PR_LDS, s, p);
             FC_HIP(hipGetLastError());
         };
         const bool k5 = in.K_pad == 160;                                // latent 300: x1 = 150 columns (the shipped configurations)
         switch (act) {
-            case FC_ACT_GELU: k5 ? go(premlp_rows_kernel<FC_ACT_GELU, 5>) : go(premlp_rows_kernel<FC_ACT_GELU, 0>); break;
-            case FC_ACT_RELU: k5 ? go(premlp_rows_kernel<FC_ACT_RELU, 5>) : go(premlp_rows_kernel<FC_ACT_RELU, 0>); break;
-            case FC_ACT_ELU: k5 ? go(premlp_rows_kernel<FC_ACT_ELU, 5>) : go(premlp_rows_kernel<FC_ACT_ELU, 0>); break;
-            case FC_ACT_LRELU02: k5 ? go(premlp_rows_kernel<FC_ACT_LRELU02, 5>) : go(premlp_rows_kernel<FC_ACT_LRELU02, 0>); break;
-            default: k5 ? go(premlp_rows_kernel<FC_ACT_NONE, 5>) : go(premlp_rows_kernel<FC_ACT_NONE, 0>); break;
+            case FC_ACT_GELU: k5 ? go(premlp_rows_kernel<FC_ACT_GELU, 5>, FC_ACT_GELU, 5) : go(premlp_rows_kernel<FC_ACT_GELU, 0>, FC_ACT_GELU, 0); break;
+            case FC_ACT_RELU: k5 ? go(premlp_rows_kernel<FC_ACT_RELU, 5>, FC_ACT_RELU, 5) : go(premlp_rows_kernel<FC_ACT_RELU, 0>, FC_ACT_RELU, 0); break;
+            case FC_ACT_ELU: k5 ? go(premlp_rows_kernel<FC_ACT_ELU, 5>, FC_ACT_ELU, 5) : go(premlp_rows_kernel<FC_ACT_ELU, 0>, FC_ACT_ELU, 0); break;
+            case FC_ACT_LRELU02: k5 ? go(premlp_rows_kernel<FC_ACT_LRELU02, 5>, FC_ACT_LRELU02, 5) : go(premlp_rows_kernel<FC_ACT_LRELU02, 0>, FC_ACT_LRELU02, 0); break;
+            default: k5 ? go(premlp_rows_kernel<FC_ACT_NONE, 5>, FC_ACT_NONE, 5) : go(premlp_rows_kernel<FC_ACT_NONE, 0>, FC_ACT_NONE, 0); break;
         }
         return;
     }

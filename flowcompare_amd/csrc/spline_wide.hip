@@ -28,8 +28,10 @@
 // transpose of those seven registers across the rows (v_permlane16_swap + v_permlane32_swap, one swap per register).  64 points x 5 dims =
 // 5 full wave evaluations (VAR 11: 6 for the same points, one half empty).
 #include "common.h"
+#include "activations.h"
 #include "spline.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace fc {
 
@@ -48,6 +50,12 @@ struct SplineWideParams {
     int col_group;
     float out_scale;             // 1 / (kOneAccActScale * 2^w1_exp)
     int ablate;                  // diagnostic knob 14: 1 no spline evaluation, 2 main loop only (results invalid)
+    // EPI 1 (a Linear layer of the coupling MLP: bias in the accumulators, residual, exact-erf GELU, output as a limb image)
+    unsigned short* out16;       // [rows][N/16][hi 16 | lo 16] fp16
+    const unsigned short* res16; // residual as a one-accumulator image of the same shape, or null (models/nets.py:27: odd hidden layers)
+    int n16;                     // 16-column blocks per row of out16 / res16
+    float s1, s2;                // output limb split: hi = rn16(v s1), lo = rn16((v s1 - hi) s2): (kOneAccActScale, 1) or (1, 2048)
+    int* ovf;                    // split-fp16 range flag (common.h Fp16Guard)
 };
 
 // column of the kernel's tile order: row kq = (c >> 2) & 3 of 16-parameter block jb = c >> 4, register r = c & 3 -> slot s = 4 jb + r
@@ -62,13 +70,13 @@ __host__ __device__ inline int spline_wide_src_col(int c) {
 
 // ---------------------------------------------------------------- weight image + bias in the kernel's order (fc_flow_create)
 __global__ __launch_bounds__(256) void spline_wide_image_kernel(const float* __restrict__ W, const float* __restrict__ bias, int n_src, int K_pad, float wscale,
-                                                                float bscale, unsigned short* __restrict__ W1, float* __restrict__ bias1, size_t n) {
+                                                                float bscale, unsigned short* __restrict__ W1, float* __restrict__ bias1, size_t n, int permute) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     const size_t row = t / K_pad;
     const int k = (int)(t - row * K_pad);
     const int tile = (int)(row >> 7), c = (int)(row & 127);
-    const int sc = spline_wide_src_col(c);
+    const int sc = permute ? spline_wide_src_col(c) : c;
     const int srow = tile * 128 + sc;
     const bool live = sc >= 0 && srow < n_src;
     const float x = live ? W[(size_t)srow * K_pad + k] * wscale : 0.f;
@@ -80,7 +88,8 @@ __global__ __launch_bounds__(256) void spline_wide_image_kernel(const float* __r
     if (k == 0) bias1[row] = live ? bias[srow] * bscale : 0.f;
 }
 
-int g_spline_wide_dma = 0;   // developer knob 27: DMA pieces per phase, 0 = {1,3,3,1} / {2,3,3,0} (shipped)
+int g_spline_wide_dma = 0;   // developer knob 27 (--dev builds): DMA pieces per phase, 0 = {2,3,3,0} / {2,3,3,0} (shipped: -1.5 % against {1,3,3,1} / {2,3,3,0}, same box)
+int g_spline_wide_colgroup = -1;   // knob 28: column-group size of the tile order in 256-column tiles (-1 = shipped: 5)
 
 // rows of 16 lanes (a0,a1,a2,a3 | b0,b1,b2,b3):  swap32 -> a = (a0,a1,b0,b1), b = (a2,a3,b2,b3) ;  swap16 -> a = (a0,b0,a2,b2), b = (a1,b1,a3,b3)
 __device__ __forceinline__ void sw_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
@@ -158,7 +167,9 @@ constexpr int SW_LDS = 4 * 32768 + 2 * 1024;      // two stages of (256 point ro
 
 // DMA pieces per LOAD segment of a k step, for the group that fetches the points (waves 0-3: P*) and the weights (waves 4-7: Q*); the
 // lagging group must not issue in its last segment (it waits for its pieces there)
-template <int P0, int P1, int P2, int P3, int Q0, int Q1, int Q2, int Q3>
+// EPI 0: the fused spline coupling; EPI 1: a 512-wide Linear layer of the coupling MLP with GELU (same main loop, same one-accumulator
+// arithmetic; the weight image in natural row order)
+template <int EPI, int P0, int P1, int P2, int P3, int Q0, int Q1, int Q2, int Q3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2)))
 void spline_wide_kernel(const SplineWideParams p) {
     static_assert(P0 + P1 + P2 + P3 == 8 && Q0 + Q1 + Q2 == 8 && Q3 == 0, "eight pieces per wave and k step");
@@ -246,8 +257,9 @@ void spline_wide_kernel(const SplineWideParams p) {
     const char* src = src_of(bm, bn);
     SW_DMA(src, 0, 0, 8)
     bias_dma(bn, 0);
-    float spl_x[5], spl_ldj;
-    load_x(bm, bn, spl_x, spl_ldj);
+    float spl_x[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, spl_ldj = 0.f;
+    if constexpr (EPI == 0) load_x(bm, bn, spl_x, spl_ldj);
+    float omax = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();                         // the second group runs one segment behind the first
@@ -315,11 +327,92 @@ void spline_wide_kernel(const SplineWideParams p) {
             dsrc = lastk ? nsrc : src + (size_t)(kt + 2) * 128;
             if (lastk && has_next) {                                    // the stream runs on into the next tile: its bias and x2 / log-det operands too
                 bias_dma(nbn, par ^ 1);
-                load_x(nbm, nbn, nx, nldj);
+                if constexpr (EPI == 0) load_x(nbm, nbn, nx, nldj);
             }
             SW_STEP(1)
         }
         // ---------------------------------------------------------------- epilogue in registers
+        // Tile boundary: group 0 has finished its last MFMA segment one barrier before group 1.  It waits that one segment out, so that BOTH
+        // groups evaluate their splines in the same interval: two waves per SIMD issue VALU work at twice the rate of one (a lone wave issues
+        // an instruction every 4 cycles), and the evaluation is ~1400 VALU instructions per wave and tile.  Group 1 then re-enters one barrier
+        // behind group 0 again.  (First form of this kernel: group 0's evaluation beside group 1's last MFMAs, group 1's beside group 0's
+        // first: the two evaluations stood in series, 0.13 of 0.63 ms per launch.)
+        if (grp == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (EPI == 1) {
+            // ---- Linear + GELU: value = acc os (+ residual), y = gelu(value), stored as the limb image the next layer copies.  A lane holds features
+            // 16 jb + 4 kq + 0..3 of point (ib, l15); one v_permlane16_swap per limb word pairs the rows kq = 2 h, 2 h + 1 so that an even row holds
+            // the hi limbs of features 8 h .. 8 h + 7 of its 16-block and the odd row their lo limbs: ONE 16-byte store per lane and block, 64
+            // contiguous bytes per point (the image's [hi 16 | lo 16] block).  The residual image is read the same way and un-swapped.
+            if (p.ablate != 2) {
+                const float os = p.out_scale, s1 = p.s1, s2 = p.s2, rinv = 1.0f / kOneAccActScale;
+                const size_t rowb = (size_t)p.n16 * 64;
+                const size_t col_off = (size_t)(bn * 16 + grp * 8) * 64 + (kq & 1) * 32 + (kq >> 1) * 16;
+                // the residual words of point block ib + 1 are requested before block ib is evaluated (two register sets): left inside the block
+                // loop every load was waited for where it was issued, ~1 us of exposed latency per block and 32 blocks per tile
+                uint4 rr[2][4];                                   // (half a point block = four 16-column blocks per set: a whole block per set spills)
+                auto res_issue = [&](int hb, uint4 (&r)[4]) {
+                    const char* src = reinterpret_cast<const char*>(p.res16) + (size_t)(bm * 256 + pw * 64 + (hb >> 1) * 16 + l15) * rowb + col_off + (hb & 1) * 256;
+#pragma unroll
+                    for (int jq = 0; jq < 4; ++jq) r[jq] = *reinterpret_cast<const uint4*>(src + jq * 64);
+                };
+                if (p.res16) res_issue(0, rr[0]);
+#pragma unroll
+                for (int hb = 0; hb < 8; ++hb) {
+                    const int ib = hb >> 1;
+                    const size_t off = (size_t)(bm * 256 + pw * 64 + ib * 16 + l15) * rowb + col_off;
+                    if (p.res16 && hb + 1 < 8) res_issue(hb + 1, rr[(hb + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int jb = (hb & 1) * 4; jb < (hb & 1) * 4 + 4; ++jb) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[ib][jb][r] * os;
+                        if (p.res16) {
+                            // even row: {hi f0-3 (own), hi f4-7 (partner's)}, odd row: {lo f0-3 (partner's), lo f4-7 (own)} -> swap back -> own hi / lo words
+                            const uint4 rw = rr[hb & 1][jb & 3];
+                            float h0 = __builtin_bit_cast(float, rw.x), h1 = __builtin_bit_cast(float, rw.y);
+                            float l0 = __builtin_bit_cast(float, rw.z), l1 = __builtin_bit_cast(float, rw.w);
+                            sw_swap16(h0, l0);
+                            sw_swap16(h1, l1);
+                            const unsigned hw[2] = {__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+                            const unsigned lw[2] = {__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const unsigned short hb = (unsigned short)(hw[r >> 1] >> (16 * (r & 1))), lb = (unsigned short)(lw[r >> 1] >> (16 * (r & 1)));
+                                v[r] += ((float)__builtin_bit_cast(_Float16, hb) + (float)__builtin_bit_cast(_Float16, lb)) * rinv;      // (hi + lo is exact in fp32)
+                            }
+                        }
+                        unsigned hw2[2], lw2[2];
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            const float y0 = fc_gelu(v[r]) * s1, y1 = fc_gelu(v[r + 1]) * s1;
+                            omax = fmaxf(omax, fmaxf(fabsf(y0), fabsf(y1)));
+                            asm volatile("" : "+v"(omax));              // (pins the running maximum here: hipcc otherwise keeps all 128 values for one reduction tree at the end and spills them)
+                            const _Float16 a0 = (_Float16)y0, a1 = (_Float16)y1;
+                            const _Float16 b0 = (_Float16)((y0 - (float)a0) * s2), b1 = (_Float16)((y1 - (float)a1) * s2);
+                            hw2[r >> 1] = (unsigned)__builtin_bit_cast(unsigned short, a0) | ((unsigned)__builtin_bit_cast(unsigned short, a1) << 16);
+                            lw2[r >> 1] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+                        }
+                        float x0 = __builtin_bit_cast(float, hw2[0]), x1 = __builtin_bit_cast(float, hw2[1]);
+                        float y0 = __builtin_bit_cast(float, lw2[0]), y1 = __builtin_bit_cast(float, lw2[1]);
+                        sw_swap16(x0, y0);
+                        sw_swap16(x1, y1);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out16) + off + jb * 64) =
+                            make_uint4(__builtin_bit_cast(unsigned, x0), __builtin_bit_cast(unsigned, x1), __builtin_bit_cast(unsigned, y0), __builtin_bit_cast(unsigned, y1));
+                        if (jb & 1) __builtin_amdgcn_sched_barrier(0);            // (left alone the scheduler interleaves all 32 blocks' GELU chains and spills the accumulators)
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
+            }
+        } else
         if (p.ablate != 2) {
             const float os = p.out_scale;
             const int t128 = 2 * bn + grp, dim0 = t128 * 5;
@@ -367,6 +460,11 @@ void spline_wide_kernel(const SplineWideParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j]));
         }
+        if (grp == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (!has_next) break;
         t = tn; bm = nbm; bn = nbn; src = nsrc; par ^= 1;
 #pragma unroll
@@ -374,6 +472,7 @@ void spline_wide_kernel(const SplineWideParams p) {
         spl_ldj = nldj;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
+    if constexpr (EPI == 1) { if (!(omax < 65504.0f) && p.ovf) atomicOr(p.ovf, 1); }      // (also on a NaN)
 #undef SW_DMA
 #undef SW_PHASE
 #undef SW_STEP
@@ -381,13 +480,13 @@ void spline_wide_kernel(const SplineWideParams p) {
 
 // ---------------------------------------------------------------- host side
 bool spline_wide_eligible(const PackedLinear& L, int K_bins) {
-    return K_bins == 8 && L.W1 != nullptr && L.bias1 != nullptr && L.nseg == 1 && L.K_pad % 64 == 0 && L.N_pad % 128 == 0;
+    return K_bins == 8 && L.W1 != nullptr && L.w1_permuted && L.bias1 != nullptr && L.nseg == 1 && L.K_pad % 64 == 0 && L.N_pad % 128 == 0;
 }
 
 // Attaches the kernel's weight image and bias to the packed spline parameter layer (K = 8 bins; W / bias hold spline.h's column order).
 // wmax = max |w| over the layer (host side, from the checkpoint tensor).
-void spline_wide_attach(DeviceArena& arena, PackedLinear& L, float wmax, hipStream_t s) {
-    if (!L.W || !L.bias || !L.W2 || L.nseg != 1 || L.K_pad % 64 != 0 || L.N_pad % 128 != 0 || L.n_alloc < L.N_pad) return;
+void spline_wide_attach(DeviceArena& arena, PackedLinear& L, float wmax, hipStream_t s, bool permute) {
+    if (!L.W || !L.bias || !L.W2 || L.nseg != 1 || L.K_pad % 64 != 0 || L.N_pad % (permute ? 128 : 256) != 0 || L.n_alloc < L.N_pad) return;
     if (!(wmax < 65504.0f)) return;
     int e = 0;
     if (wmax > 0.f) {
@@ -399,7 +498,8 @@ void spline_wide_attach(DeviceArena& arena, PackedLinear& L, float wmax, hipStre
     L.W1 = (unsigned short*)arena.alloc_bytes(n * 2 * sizeof(unsigned short));
     L.bias1 = arena.alloc_floats((size_t)rows);
     L.w1_exp = e;
-    spline_wide_image_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(L.W, L.bias, L.N_pad, L.K_pad, ldexpf(1.f, e), kOneAccActScale * ldexpf(1.f, e), L.W1, L.bias1, n);
+    L.w1_permuted = permute;
+    spline_wide_image_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(L.W, L.bias, L.N_pad, L.K_pad, ldexpf(1.f, e), kOneAccActScale * ldexpf(1.f, e), L.W1, L.bias1, n, permute ? 1 : 0);
     FC_HIP(hipGetLastError());
 }
 
@@ -420,9 +520,18 @@ void launch_spline_wide(const PackedLinear& L, const GemmEpi& e, int rows_alloc,
     p.col_group = (p.nbm % 8 == 0 && p.nbn > 5) ? 5 : 0;
     p.out_scale = 1.0f / (kOneAccActScale * ldexpf(1.f, L.w1_exp));
     p.ablate = g_spline_ablate;
-    static PerDeviceOnce attr_once, slots_once;
-    auto kern = spline_wide_kernel<1, 3, 3, 1, 2, 3, 3, 0>;
-    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS)); return 0; });
+    if (g_spline_wide_colgroup >= 0) p.col_group = (p.nbm % 8 == 0 && p.nbn > g_spline_wide_colgroup) ? g_spline_wide_colgroup : 0;
+    static PerDeviceOnce slots_once;
+    void (*kern)(const SplineWideParams) = spline_wide_kernel<0, 2, 3, 3, 0, 2, 3, 3, 0>;
+    FC_DEV(if (g_spline_wide_dma == 1) kern = spline_wide_kernel<0, 2, 2, 2, 2, 3, 3, 2, 0>;
+           else if (g_spline_wide_dma == 2) kern = spline_wide_kernel<0, 0, 3, 3, 2, 3, 3, 2, 0>;
+           else if (g_spline_wide_dma == 3) kern = spline_wide_kernel<0, 1, 3, 3, 1, 2, 3, 3, 0>;
+           else if (g_spline_wide_dma == 4) kern = spline_wide_kernel<0, 1, 2, 3, 2, 2, 3, 3, 0>;)
+    {
+        static PerDeviceOnce attr_once[5];
+        attr_once[g_spline_wide_dma >= 0 && g_spline_wide_dma < 5 ? g_spline_wide_dma : 0].run(
+            [&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS)); return 0; });
+    }
     const int slots = slots_once.run([](int dev) {
         int cus = 0;
         FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -432,9 +541,72 @@ void launch_spline_wide(const PackedLinear& L, const GemmEpi& e, int rows_alloc,
     int grid = p.nbm * p.nbn;
     if (grid > slots) grid = slots;
     const double flops = 2.0 * (double)(e.rows_valid > 0 ? e.rows_valid : rows_alloc) * (double)(L.n_true ? L.n_true : L.N_pad) * (double)(L.k_true ? L.k_true : L.K_pad);
-    ProfScope ps("void fc::spline_wide_kernel<1, 3, 3, 1, 2, 3, 3, 0>(fc::SplineWideParams)", flops, 0.0, s);
+    ProfScope ps("void fc::spline_wide_kernel<0, 2, 3, 3, 0, 2, 3, 3, 0>(fc::SplineWideParams)", flops, 0.0, s);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SW_LDS, s, p);
     FC_HIP(hipGetLastError());
+}
+
+}  // namespace fc
+
+namespace fc {
+
+// ---------------------------------------------------------------- EPI 1: a GELU Linear layer of the coupling MLP on the same tile
+int g_linear_wide = 0;       // knob 29: 0 = off (SHIPPED: measured, not faster -- below), 1 = hidden layers of 512-wide coupling nets on this kernel for scenes of at
+                             // least 2048 target points (the gate is the scene's size, never the batch's), 2 = at any size (tests)
+// Measured on C2 (16 x 4096, same box, profiles/r04o_*): 133 us per hidden-layer launch = ~75 us of main loop (459 TF-eq at N = 512:
+// profiles/micro/wide_gemm_probe.hip) + ~55 us of epilogue that nothing overlaps (4471 VALU instructions per wave and tile: 128 exact-erf
+// GELUs, limb splits, lane swaps; with one workgroup per CU there is no second tile's main loop to hide them behind), and the in_layer stays
+// on its fp32-A loop (100 us): 30.6 + 11.5 = 42 ms per step against 40.8 ms for the row-resident chain (mlprows.hip), whose epilogue runs
+// in micro-steps under the next block's MFMAs.  The arithmetic also differs from the chain's (one accumulator, k32 MFMAs), so shipping it for
+// large scenes only would make a row's log-prob depend on the size of the scene it sits in (tests/test_gpu_fullsize.py compares rows of a
+// 512-point run with the 16 x 4096 run bit for bit).  Kept behind the knob with its tests; not on the default path.
+int gemm_linear_wide_knob() { return g_linear_wide; }
+
+bool linear_wide_eligible(const PackedLinear& L, const GemmEpi& e, int rows_alloc) {
+    return L.W1 && !L.w1_permuted && L.bias1 && L.nseg == 1 && L.K_pad % 64 == 0 && L.N_pad % 256 == 0 && rows_alloc % 256 == 0 && e.A16 &&
+           e.a16_scale == kOneAccActScale && e.C16 && !e.C && !e.Cpre && !e.gradu && !e.residual && !e.rowscal && e.act == FC_ACT_GELU &&
+           (!e.residual16 || (e.r16_scale == kOneAccActScale && e.ldr16 == L.N_pad)) && (e.c16_scale == 0.f || e.c16_scale == kOneAccActScale);
+}
+
+void launch_linear_wide(const PackedLinear& L, const GemmEpi& e, int rows_alloc, hipStream_t s) {
+    if (!linear_wide_eligible(L, e, rows_alloc)) throw Error(FC_ERR_INVALID, "launch_linear_wide: needs one-accumulator images in and out, GELU, N % 256 == 0, K % 64 == 0, rows % 256 == 0");
+    int* flag = gemm_fp16_flag();
+    if (!flag) throw Error(FC_ERR_INVALID, "launch_linear_wide: needs an open split-fp16 guard scope");
+    SplineWideParams p{};
+    p.A16 = e.A16; p.W1 = L.W1; p.bias1 = L.bias1;
+    p.KT = L.K_pad / 32;
+    p.nbm = rows_alloc / 256;
+    p.nbn = L.N_pad / 256;
+    p.ntile128 = L.N_pad / 128;
+    p.col_group = (p.nbm % 8 == 0) ? p.nbn : 0;      // (a 512-wide layer: both column tiles of a row tile side by side on one XCD)
+    p.out_scale = 1.0f / (kOneAccActScale * ldexpf(1.f, L.w1_exp));
+    p.ablate = g_spline_ablate == 2 ? 2 : 0;
+    p.out16 = e.C16; p.res16 = e.residual16; p.n16 = L.N_pad / 16;
+    p.s1 = e.c16_scale > 0.f ? e.c16_scale : 1.0f;
+    p.s2 = e.c16_scale > 0.f ? 1.0f : 2048.0f;
+    p.ovf = flag;
+    static PerDeviceOnce attr_once, slots_once;
+    auto kern = spline_wide_kernel<1, 2, 3, 3, 0, 2, 3, 3, 0>;
+    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS)); return 0; });
+    const int slots = slots_once.run([](int dev) {
+        int cus = 0;
+        FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int n = cus & ~7;
+        return n < 8 ? 8 : n;
+    });
+    int grid = p.nbm * p.nbn;
+    if (grid > slots) grid = slots;
+    const double flops = 2.0 * (double)(e.rows_valid > 0 ? e.rows_valid : rows_alloc) * (double)(L.n_true ? L.n_true : L.N_pad) * (double)(L.k_true ? L.k_true : L.K_pad);
+    ProfScope ps("void fc::spline_wide_kernel<1, 2, 3, 3, 0, 2, 3, 3, 0>(fc::SplineWideParams)", flops, 0.0, s);
+    static const bool trace = getenv("FC_FLAG_TRACE") != nullptr;
+    int before = 0, after = 0;
+    if (trace) { FC_HIP(hipStreamSynchronize(s)); FC_HIP(hipMemcpy(&before, flag, 4, hipMemcpyDeviceToHost)); }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SW_LDS, s, p);
+    FC_HIP(hipGetLastError());
+    if (trace) {
+        FC_HIP(hipStreamSynchronize(s)); FC_HIP(hipMemcpy(&after, flag, 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[flag trace] linear_wide rows %d N %d res %d s1 %g: flag %d -> %d\n", rows_alloc, L.N_pad, e.residual16 != nullptr, p.s1, before, after);
+    }
 }
 
 }  // namespace fc

@@ -457,7 +457,8 @@ def op_linear(x, W, bias=None, residual=None, act="none"):
 
 def op_mlp_hidden(x0, x1, state_dict, rowscal=None, act="gelu", use_rows=True):
     """Last hidden activation [rows, 512] of a 512-wide reference MLP over cat(x0, x1) (fc_op_mlp_hidden_f32); `state_dict` holds
-    net.in_layer / net.layers.<i> / net.out_layer tensors (host or device; copied to the host), optionally net.colvec."""
+    net.in_layer / net.layers.<i> / net.out_layer tensors (host or device; copied to the host), optionally net.colvec.
+    use_rows: True = the row-resident chain kernel, False = one launch per layer, "wide" = hidden layers on the 256 x 256 one-accumulator kernel."""
     code = {"none": 0, "gelu": 1, "relu": 2, "elu": 3, "lrelu": 4}[act]
     x0 = _dev_f32(x0)
     x1 = _dev_f32(x1) if x1 is not None else None
@@ -467,7 +468,7 @@ def op_mlp_hidden(x0, x1, state_dict, rowscal=None, act="gelu", use_rows=True):
     arr, keep = _tensor_table({k: v.detach().cpu() for k, v in state_dict.items()})
     with torch.cuda.device(x0.device):
         _check(lib().fc_op_mlp_hidden_f32(_ptr(x0), x0.shape[1], _ptr(x1), x1.shape[1] if x1 is not None else 0, _ptr(rs), arr, len(arr),
-                                          _ptr(out), rows, code, int(bool(use_rows)), _stream()))
+                                          _ptr(out), rows, code, 2 if use_rows == "wide" else int(bool(use_rows)), _stream()))
     del keep
     return out
 

@@ -166,9 +166,16 @@ class GradientReducer:
             local = cached[1]                                     # (same pattern, flag 0: the device copy of the previous step)
         mask = local.clone()
         work = dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        timed = getattr(self, "time_exposed", False) and self.flat[0].is_cuda
+        if timed:                                                 # how long the compute stream stands waiting for the collectives: their EXPOSED time
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self.inflight:
             w.wait()
         work.wait()
+        if timed:
+            e1.record()
+            self.exposed_events = getattr(self, "exposed_events", []) + [(e0, e1)]
         if bool(mask[-1].item() != 0.0) or cached is None:        # some rank's pattern changed: every rank re-reads the reduced mask
             absent = [m == 0.0 for m in mask[:-1].cpu().tolist()]
             steady = torch.tensor(self.present + [0.0], dtype=torch.float32).to(self.flat[0].device)
@@ -179,9 +186,29 @@ class GradientReducer:
                 p.grad = None
         self.reset()
 
+    def exposed_ms(self):
+        """Milliseconds per finish() the compute stream waited for gradient collectives (time_exposed = True; synchronises), or None."""
+        ev = getattr(self, "exposed_events", [])
+        if not ev:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in ev]
+        self.exposed_events = []
+        return sum(ms) / len(ms)
+
     def remove(self):
         for h in self.hooks:
             h.remove()
+
+
+def device_census(identity, group=None):
+    """Proof that the N ranks of a run sit on N different devices: every rank contributes what identifies its GPU (bench.py: UUID / PCI
+    address) and every rank gets {"world": N, "unique_devices": number of distinct identities} back (one all_gather_object: RCCL on the GPU
+    box, gloo in the CPU tests)."""
+    world = dist.get_world_size(group)
+    got = [None] * world
+    dist.all_gather_object(got, str(identity), group=group)
+    return {"world": world, "unique_devices": len(set(got))}
 
 
 class FlatAdam:

@@ -362,7 +362,8 @@ static float time_kernel(KERN kern, const WideParams& p, int grid, int reps) {
 }
 
 int main(int argc, char** argv) {
-    const int K = 512, N = 3840, rows = argc > 1 ? atoi(argv[1]) : 65536, vrows = 2048;
+    const int K = 512, rows = argc > 1 ? atoi(argv[1]) : 65536, vrows = 2048, N = argc > 2 ? atoi(argv[2]) : 3840;      // (N = 512: a hidden layer of the coupling MLP)
+    const bool timing_only = argc > 3;
     std::mt19937 g(7);
     std::normal_distribution<float> nd(0.f, 1.f);
     int cus = 0;
@@ -385,6 +386,7 @@ int main(int argc, char** argv) {
 
     // ---------------- accuracy: 2048 rows, three weight scales, against fp64 and an fp32 fmaf chain (sampled columns)
     for (float wamp : {0.04f, 0.4f, 0.004f}) {
+        if (timing_only) break;
         std::vector<float> A((size_t)vrows * K), W((size_t)N * K);
         std::uniform_real_distribution<float> ud(-wamp, wamp);
         for (auto& v : A) { float x = nd(g); v = x > 0 ? x : 0.05f * x; }
@@ -454,7 +456,9 @@ int main(int argc, char** argv) {
                         {"lock, no MFMA", wide_kernel<0, 2, 2, 2, 2, 2, 2, 2, 2, 1, 3>}};
         for (auto& v : vs) CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.k), hipFuncAttributeMaxDynamicSharedMemorySize, 133120));
         for (int cg : {5}) {
+            if (N / 256 <= cg) cg = N / 256;
             WideParams p{dA, dW, nullptr, 0, K / 32, rows / 256, N / 256, cg, 1.f, dS};
+            if (p.nbm % 8 != 0) { printf("rows %d: row tiles not a multiple of 8, skipped\n", rows); continue; }
             const int grid = std::min(slots, p.nbm * p.nbn);
             for (auto& v : vs) {
                 const float a = time_kernel(v.k, p, grid, 20);

@@ -37,3 +37,24 @@ def test_bench_prints_one_json_line_with_roofline_cpu_baseline_and_train():
     tr = j["train"]
     assert "error" not in tr, tr
     assert tr["steps"] == 1 and tr["ms_per_step"] > 0 and tr["points_per_sec"] > 0 and tr["peak_mem_GiB"] > 0 and tr["loss"] == tr["loss"]
+
+
+def test_training_leg_as_guarded_second_phase_and_device_census():
+    """What a multi-rank run does, on one rank: the forward line first (kept in memory), then the training leg in a CHILD process with its own RCCL
+    process group (bench.py --train-in-child); still ONE line on stdout, with the `train` object from the child (all-reduce exposed time included)
+    and the `rccl` census (world 1, 1 distinct device).  Under torch.distributed.run the same path runs with N ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29611",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--layers", "2", "--batch", "2", "--points", "256", "--ctx-points", "320",
+           "--train-steps", "1", "--train-in-child", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, f"stdout must carry exactly one JSON line, got {len(lines)}: {r.stdout[:400]}"
+    j = json.loads(lines[0])
+    assert j["rccl"]["world"] == 1 and j["rccl"]["unique_devices"] == 1
+    assert j["config"]["points_per_scene"] == 256 and j["config"]["context_points_per_scene"] == 320
+    tr = j["train"]
+    assert "error" not in tr, tr
+    assert tr["steps"] == 1 and tr["ms_per_step"] > 0 and "child" in tr["phase"] and tr["all_reduce_exposed_ms_per_step"] is not None
+    for k in j["kernels"]:
+        assert "frac" in k and "traffic" in k and ("traffic_unit" in k or "traffic_note" in k)

@@ -92,6 +92,28 @@ def test_row_resident_mlp_chain_matches_fp64_and_the_per_layer_launches(rows, k0
     assert torch.equal(y2, y_rows), "the row-resident chain is not deterministic"
 
 
+@pytest.mark.parametrize("rows,k0,k1,n_mid,extra", [(1000, 150, 64, 2, False), (300, 150, 64, 4, True), (5000, 150, 64, 2, True), (256, 512, 0, 1, False)])
+def test_wide_linear_layers_match_fp64_and_the_per_layer_path(rows, k0, k1, n_mid, extra):
+    """Hidden layers of a 512-wide coupling net on the 256 x 256 one-accumulator kernel (spline_wide.hip EPI 1: k32 MFMAs, one fp32 accumulator,
+    bias in the accumulator start, residual read from the previous image, exact-erf GELU, output as a limb image) against fp64 and against
+    the per-layer 128 x 128 launches (another arithmetic: agreement within fp32 noise, not bit for bit).  5000 rows = 20 row tiles x 2 column
+    tiles: several tiles per persistent workgroup order; the rows of a smaller call must reproduce bit for bit."""
+    sd = _mlp_state(k0 + k1, n_mid, seed=9, colvec=extra)
+    x0, x1 = _rand(rows, k0, seed=11, scale=2.0), (_rand(rows, k1, seed=12) if k1 else None)
+    rs = (_rand(rows, seed=13) * 7 + 7.5) if extra else None
+    ref = _mlp_ref(x0 if x1 is None else torch.cat((x0, x1), 1), sd, n_mid, rs)
+    args = (x0.to(DEV), None if x1 is None else x1.to(DEV), sd, None if rs is None else rs.to(DEV))
+    y_wide = engine.op_mlp_hidden(*args, use_rows="wide").cpu().double()
+    y_gemm = engine.op_mlp_hidden(*args, use_rows=False).cpu().double()
+    scale = ref.abs().max().item()
+    e_wide, e_gemm = (y_wide - ref).abs().max().item(), (y_gemm - ref).abs().max().item()
+    print(f"rows {rows} K {k0}+{k1} hidden layers {n_mid}: |wide - fp64| {e_wide:.2e} mean {(y_wide - ref).abs().mean().item():.2e}  |per-layer - fp64| {e_gemm:.2e} mean {(y_gemm - ref).abs().mean().item():.2e}  (max |h| {scale:.2f})")
+    assert e_wide < 2e-5 * max(1.0, scale)
+    assert (y_wide - ref).abs().mean().item() < 1.5 * (y_gemm - ref).abs().mean().item() + 1e-8
+    part = engine.op_mlp_hidden(x0[:200].to(DEV), None if x1 is None else x1[:200].to(DEV), sd, None if rs is None else rs[:200].to(DEV), use_rows="wide").cpu().double()
+    assert torch.equal(part, y_wide[:200]), "a row's result depends on the call it sits in (wide Linear kernel)"
+
+
 def test_row_resident_mlp_chain_rows_are_independent():
     """Each wave of the chain kernel owns 32 rows for the whole chain: a row's result must not depend on which band / workgroup it sits in."""
     sd = _mlp_state(214, 2, seed=5)
