@@ -17,7 +17,7 @@ struct TmpBuf {
 }  // namespace fc
 
 
-namespace fc { long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; extern int g_spline_wide_dma; extern int g_spline_wide_colgroup; extern int g_linear_wide; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
+namespace fc { void one_acc_gemm_debug(const float*, const float*, const float*, float, float*, int, int, int, hipStream_t); long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; extern int g_spline_wide_dma; extern int g_spline_wide_colgroup; extern int g_linear_wide; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }
 
 extern "C" {
@@ -54,6 +54,14 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 14) fc::g_spline_ablate = value;     /* diagnostic: 1 = fused spline epilogue without the spline evaluation, 2 = main loop only (results invalid) */
     else return FC_ERR_INVALID;
     return FC_OK;
+}
+
+/* diagnostic / test entry (not part of fcflow.h): out[rows, N] = x[rows, K] W[N, K]^T + bias through the ONE-ACCUMULATOR limb form on the 256 x 256 main loop of
+   spline_wide.hip, nothing else -- the product the fused spline layer is built on, measurable against fp64 by itself; device pointers, wmax = max |W| */
+int fc_debug_one_acc_gemm_f32(const float* x, const float* W, const float* bias, float wmax, float* out, int32_t rows, int32_t N, int32_t K, void* stream) {
+    FC_API_BEGIN
+    fc::one_acc_gemm_debug(x, W, bias, wmax, out, rows, N, K, (hipStream_t)stream);
+    FC_API_END
 }
 
 /* 1 when the library was built with the developer kernel variants (-DFC_DEV_VARIANTS) */

@@ -56,6 +56,8 @@ struct SplineWideParams {
     int n16;                     // 16-column blocks per row of out16 / res16
     float s1, s2;                // output limb split: hi = rn16(v s1), lo = rn16((v s1 - hi) s2): (kOneAccActScale, 1) or (1, 2048)
     int* ovf;                    // split-fp16 range flag (common.h Fp16Guard)
+    // EPI 2 (plain product, fc_debug_one_acc_gemm_f32: the one-accumulator limb form by itself, for the accuracy test)
+    float* C; int ldc;
 };
 
 // column of the kernel's tile order: row kq = (c >> 2) & 3 of 16-parameter block jb = c >> 4, register r = c & 3 -> slot s = 4 jb + r
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void spline_wide_image_kernel(const float* __r
     const size_t blk = row * (K_pad / 16) + k / 16;
     W1[blk * 32 + (k & 15)] = __builtin_bit_cast(unsigned short, h);
     W1[blk * 32 + 16 + (k & 15)] = __builtin_bit_cast(unsigned short, l);
-    if (k == 0) bias1[row] = live ? bias[srow] * bscale : 0.f;
+    if (k == 0 && bias1) bias1[row] = live && bias ? bias[srow] * bscale : 0.f;
 }
 
 int g_spline_wide_dma = 0;   // developer knob 27 (--dev builds): DMA pieces per phase, 0 = {2,3,3,0} / {2,3,3,0} (shipped: -1.5 % against {1,3,3,1} / {2,3,3,0}, same box)
@@ -342,6 +344,16 @@ void spline_wide_kernel(const SplineWideParams p) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (EPI == 2) {
+            const float os = p.out_scale;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                float* cr = p.C + (size_t)(bm * 256 + pw * 64 + ib * 16 + l15) * p.ldc + bn * 256 + grp * 128 + 4 * kq;
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb)
+                    *reinterpret_cast<float4*>(cr + jb * 16) = make_float4(acc[ib][jb][0] * os, acc[ib][jb][1] * os, acc[ib][jb][2] * os, acc[ib][jb][3] * os);
+            }
+        } else
         if constexpr (EPI == 1) {
             // ---- Linear + GELU: value = acc os (+ residual), y = gelu(value), stored as the limb image the next layer copies.  A lane holds features
             // 16 jb + 4 kq + 0..3 of point (ib, l15); one v_permlane16_swap per limb word pairs the rows kq = 2 h, 2 h + 1 so that an even row holds
@@ -607,6 +619,50 @@ void launch_linear_wide(const PackedLinear& L, const GemmEpi& e, int rows_alloc,
         FC_HIP(hipStreamSynchronize(s)); FC_HIP(hipMemcpy(&after, flag, 4, hipMemcpyDeviceToHost));
         fprintf(stderr, "[flag trace] linear_wide rows %d N %d res %d s1 %g: flag %d -> %d\n", rows_alloc, L.N_pad, e.residual16 != nullptr, p.s1, before, after);
     }
+}
+
+}  // namespace fc
+
+namespace fc {
+
+// ---------------------------------------------------------------- EPI 2: the one-accumulator limb product by itself (debug ABI, accuracy tests)
+// out[rows, N] = x[rows, K] W[N, K]^T + bias on the 256 x 256 main loop: x and W are split into one-accumulator images here (x by
+// kOneAccActScale, W by the power of two that puts max |w| into [2^14, 2^15) -- wmax given by the caller), rows / N padded to 256.
+namespace { struct SwTmp { void* p = nullptr; explicit SwTmp(size_t b) { FC_HIP(hipMalloc(&p, b ? b : 4)); } ~SwTmp() { (void)hipFree(p); } float* f() const { return (float*)p; } }; }
+void one_acc_gemm_debug(const float* x, const float* W, const float* bias, float wmax, float* out, int rows, int N, int K, hipStream_t s) {
+    if (!x || !W || !out || rows < 1 || N < 1 || K < 64 || K % 64 != 0 || N % 256 != 0 || !(wmax < 65504.0f)) throw Error(FC_ERR_INVALID, "one_acc_gemm_debug: K % 64 == 0, N % 256 == 0");
+    const int rp = round_up(rows, 256);
+    int e = 0;
+    if (wmax > 0.f) {
+        while (ldexpf(wmax, e) >= 32768.0f) --e;
+        while (ldexpf(wmax, e) < 16384.0f && e < 100) ++e;
+    }
+    SwTmp xa((size_t)rp * K * 4), wi((size_t)N * K * 4), b1((size_t)N * 4), cp((size_t)rp * N * 4), xp((size_t)rp * K * 4);
+    launch_fill(xp.f(), 0.f, (size_t)rp * K, s);
+    FC_HIP(hipMemcpyAsync(xp.f(), x, (size_t)rows * K * 4, hipMemcpyDeviceToDevice, s));
+    const size_t nx = (size_t)rp * K, nw = (size_t)N * K;
+    spline_wide_image_kernel<<<dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s>>>(xp.f(), nullptr, rp, K, kOneAccActScale, 0.f, (unsigned short*)xa.p, nullptr, nx, 0);
+    spline_wide_image_kernel<<<dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s>>>(W, bias, N, K, ldexpf(1.f, e), kOneAccActScale * ldexpf(1.f, e), (unsigned short*)wi.p, b1.f(), nw, 0);
+    FC_HIP(hipGetLastError());
+    SplineWideParams p{};
+    p.A16 = (const unsigned short*)xa.p; p.W1 = (const unsigned short*)wi.p; p.bias1 = b1.f();
+    p.KT = K / 32; p.nbm = rp / 256; p.nbn = N / 256; p.ntile128 = N / 128;
+    p.col_group = (p.nbm % 8 == 0 && p.nbn > 5) ? 5 : 0;
+    p.out_scale = 1.0f / (kOneAccActScale * ldexpf(1.f, e));
+    p.C = cp.f(); p.ldc = N;
+    static PerDeviceOnce attr_once;
+    auto kern = spline_wide_kernel<2, 2, 3, 3, 0, 2, 3, 3, 0>;
+    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS)); return 0; });
+    int cus = 0, dev = 0;
+    FC_HIP(hipGetDevice(&dev));
+    FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int grid = p.nbm * p.nbn;
+    const int slots = (cus & ~7) < 8 ? 8 : (cus & ~7);
+    if (grid > slots) grid = slots;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SW_LDS, s, p);
+    FC_HIP(hipGetLastError());
+    FC_HIP(hipMemcpyAsync(out, cp.f(), (size_t)rows * N * 4, hipMemcpyDeviceToDevice, s));
+    FC_HIP(hipStreamSynchronize(s));
 }
 
 }  // namespace fc

@@ -37,7 +37,14 @@ def main():
                   "mfma_busy": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc),
                   "mfma_insts_per_launch": c.get("SQ_INSTS_MFMA", 0.0) / n[k], "valu_insts_per_launch": c.get("SQ_INSTS_VALU", 0.0) / n[k]}
     out = dict(sorted(out.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"]))
-    json.dump(out, open(sys.argv[2], "w"), indent=1)
+    for v in out.values():
+        v["mfma_busy_frac"] = v["mfma_busy"]
+    import datetime
+    # argv[3]: build label, argv[4]: workload key as bench.py spells it ("<config> <B> x <N> + <M>"): bench.py only quotes a table of its own workload
+    json.dump({"unit_note": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 pipes x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE / 8 / traced duration",
+               "measured": {"label": sys.argv[3] if len(sys.argv) > 3 else "", "date": datetime.date.today().isoformat(),
+                            "workload": sys.argv[4] if len(sys.argv) > 4 else "c2_dgcnn_attn_spline 16 x 4096 + 4096"},
+               "kernels": out}, open(sys.argv[2], "w"), indent=1)
     for k, v in list(out.items())[:8]:
         print(f"{v['mfma_busy'] * 100:5.1f} % MFMA busy  {v['clock_ghz'] or 0:4.2f} GHz  {v['avg_us']:8.1f} us  {k[:80]}")
 

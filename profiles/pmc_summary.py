@@ -37,7 +37,8 @@ def main():
         out[k] = e
     import datetime
     json.dump({"unit_note": "FETCH raw KB doubled (gfx950), WRITE as read; per dispatch averages",
-               "measured": {"label": sys.argv[4] if len(sys.argv) > 4 else "", "date": datetime.date.today().isoformat()},
+               "measured": {"label": sys.argv[4] if len(sys.argv) > 4 else "", "date": datetime.date.today().isoformat(),
+                            "workload": sys.argv[5] if len(sys.argv) > 5 else "c2_dgcnn_attn_spline 16 x 4096 + 4096"},
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, e in list(out.items())[:8]:
         print(f"{e['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch  {k[:90]}")

@@ -104,6 +104,22 @@ def test_c4_extra_context_at_8_scenes_of_4096_points():
     _rows_vs_oracle("C4 8 x 4096 x 115 affine layers + extra context, scene 0 rows 0..511", cfg, md, e0, e1, extra, eps, lp, 512)
 
 
+def test_reference_native_training_shape_20_scenes_of_1024_target_and_1250_context_points():
+    """The batch every FlowCompare user runs (config/dulcet-universe.yaml:1-3, 44-46, 185-187: batch_size 20, sample_size 1024, 1250 context
+    points; N != M): dulcet's model (DGCNN + attention + extra context, 115 affine layers), the whole shape through the HIP path; rows of scene
+    0 against the fp64 oracle on the full 1250-point context, determinism, and scenes 7..8 alone reproduce their rows of the 20-scene batch."""
+    B, N, M = 20, 1024, 1250
+    cfg, md = build_conditioned("c4_dgcnn_attn_extra_affine", N, DEV, cond_points=N)
+    e0, e1, extra, eps = synth_pairs(B, M, N, 43)
+    assert e0.shape == (B, M, 6) and e1.shape == (B, N, 6)
+    lp, _ = _run(cfg, md, e0, e1, extra, eps)
+    lp2, _ = _run(cfg, md, e0, e1, extra, eps)
+    assert lp.shape == (B, N) and torch.isfinite(lp).all() and torch.equal(lp, lp2)
+    lps, _ = _run(cfg, md, e0, e1, extra, eps, slice(7, 9))
+    assert torch.equal(lps, lp[7:9])
+    _rows_vs_oracle("native shape 20 x 1024 target / 1250 context x 115 affine layers + extra context, scene 0 rows 0..511", cfg, md, e0, e1, extra, eps, lp, 512)
+
+
 # ------------------------------------------------------------------------------------------------ C5
 M5 = 16384
 

@@ -136,6 +136,40 @@ def test_linear_is_linear_and_exact_on_integers():
     assert torch.equal(y, x @ W.t())
 
 
+@pytest.mark.parametrize("wamp", [0.04, 0.4, 0.004])
+def test_one_accumulator_limb_form_is_at_least_as_accurate_as_an_fp32_fmaf_chain(wamp):
+    """The product the round-4 fused spline layer is built on (spline_wide.hip), by itself: operands as hi + lo fp16 limbs with the low limb
+    UNSCALED, pre-scaled by exact powers of two (activations by 16, weights so that max |w| lands in [2^14, 2^15)), the three limb products of
+    a k32 step into ONE fp32 accumulator on v_mfma_f32_16x16x32_f16.  On the three weight scales of profiles/micro/one_acc_probe.hip, with
+    GELU-like activations (many small values: the case an unscaled low limb is weakest at), K = 512, N = 3840: maximum and mean error against
+    fp64 must not exceed those of a sequential fp32 fmaf chain (what the fp32-input MFMA computes, bit for bit) -- measured 0.6-0.7 x."""
+    L = engine.lib()
+    rows, N, K = 1024, 3840, 512
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(rows, K, generator=g)
+    x = torch.where(a > 0, a, 0.05 * a)
+    W = (torch.rand(N, K, generator=g) * 2 - 1) * wamp
+    b = (torch.rand(N, generator=g) * 2 - 1) * 0.1
+    ref = x.double() @ W.double().t() + b.double()
+    # the fp32 fmaf chain, k ascending, on a sample of columns (a python loop over k on [rows, 96] panels)
+    cols = torch.arange(5, N, 40)
+    acc = b[cols].repeat(rows, 1).clone()
+    Wc = W[cols]
+    for k in range(K):
+        acc = torch.addcmul(acc.double(), x[:, k:k + 1].double(), Wc[:, k][None].double()).float()     # one rounding per product-sum: fmaf
+    e_chain = (acc.double() - ref[:, cols]).abs()
+    out = torch.empty(rows, N, dtype=torch.float32, device=DEV)
+    xd, Wd, bd = x.to(DEV), W.to(DEV), b.to(DEV)
+    L.fc_debug_one_acc_gemm_f32.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_float, ctypes.c_void_p] + [ctypes.c_int32] * 3 + [ctypes.c_void_p]
+    with torch.cuda.device(DEV):
+        engine._check(L.fc_debug_one_acc_gemm_f32(engine._ptr(xd), engine._ptr(Wd), engine._ptr(bd), float(W.abs().max()), engine._ptr(out), rows, N, K, engine._stream()))
+    e_one = (out.cpu().double() - ref).abs()
+    print(f"weights U(-{wamp}, {wamp}), max |C| {ref.abs().max():.3f}: one accumulator max {e_one.max():.2e} mean {e_one.mean():.2e} (sampled columns: max {e_one[:, cols].max():.2e} mean {e_one[:, cols].mean():.2e})"
+          f" | fp32 fmaf chain max {e_chain.max():.2e} mean {e_chain.mean():.2e}")
+    assert e_one[:, cols].max().item() <= e_chain.max().item() and e_one[:, cols].mean().item() <= e_chain.mean().item()
+    assert e_one.max().item() <= 1.5 * e_chain.max().item()          # (all 3840 columns against the sampled chain's worst)
+
+
 def test_split_variants_match_fp64_like_fp32():
     """The split GEMM main loops -- 2 fp16 limbs / 3 MFMAs per product block (variant 5, the default) and 3 bf16 limbs / 6 MFMAs
     (variant 3, its unbounded-range fallback) -- must be as accurate as the fp32-input MFMA loop (variant 2)."""
