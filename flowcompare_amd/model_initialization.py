@@ -137,19 +137,40 @@ def initialize_flow(config, device="cuda", mode="train"):
     else:
         input_embedder.eval()
         flow.eval()
+    sharded = False
     if config["data_parallel"]:
-        raise NotImplementedError("flowcompare_amd shards scenes one-process-per-GPU (flowcompare_amd.shard); "
-                                  "nn.DataParallel (model_initialization.py:186-188) is not supported")
+        # model_initialization.py:186-188 wraps both modules in nn.DataParallel (one process, one thread per GPU).  Here the same request means
+        # scene sharding with ONE PROCESS PER GPU (flowcompare_amd/shard.py: this rank's scenes on its own device, no data-path collective, RCCL
+        # only for the loss scalar and the gradient all-reduce): under `python -m torch.distributed.run --nproc-per-node N` every rank builds the
+        # same replica on its LOCAL_RANK's device and inner_loop shards the global batch; outside a process group there is nothing to shard over.
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("config['data_parallel'] is true but no torch.distributed process group is initialised: flowcompare_amd shards scenes with one "
+                               "process per GPU -- launch with `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` and "
+                               "call torch.distributed.init_process_group('nccl') before initialize_flow (nn.DataParallel's one-process threading, "
+                               "model_initialization.py:186-188, has no counterpart here)")
+        sharded = True
     input_embedder = input_embedder.to(device)
     flow = flow.to(device)
 
     parameters = list(input_embedder.parameters()) + list(flow.parameters())
     print(f"Number of trainable parameters: {sum(p.numel() for p in parameters)}")
-    return {"parameters": parameters, "flow": flow, "input_embedder": input_embedder}
+    md = {"parameters": parameters, "flow": flow, "input_embedder": input_embedder}
+    if sharded:
+        md["sharded"] = True                                  # inner_loop then takes a GLOBAL batch and runs this rank's scenes (shard.sharded_inner_loop)
+    return md
 
 
 def inner_loop(batch, models_dict, config, eps=None):
     """model_initialization.py:206-228.  `eps` (optional) pins the augmenter noise."""
+    if models_dict.get("sharded") and not models_dict.get("_in_shard"):
+        # config['data_parallel']: `batch` is the GLOBAL batch, every rank runs its own scenes; returns (global loss, LOCAL log_prob, global bpd)
+        from . import shard
+        models_dict["_in_shard"] = True
+        try:
+            return shard.sharded_inner_loop(batch, models_dict, config, eps=eps)
+        finally:
+            models_dict["_in_shard"] = False
     extract_0, extract_1, extra_context = batch
     Din = config["input_dim"]
     extract_0, extract_1 = extract_0[:, :, :Din], extract_1[:, :, :Din]

@@ -324,7 +324,8 @@ class Flow(nn.Module):
             # inference engine below has no backward
             from . import train_flow
             return train_flow.flow_log_prob(self, x, context, extra_context, eps)
-        return self._engine().log_prob(x, context, extra_context, eps)
+        from . import library_ops                          # the inference call as a torch.library op (torch.ops.flowcompare_amd.flow_log_prob)
+        return torch.ops.flowcompare_amd.flow_log_prob(x, context, extra_context, list(eps), library_ops.register(self._engine()))
 
     def sample(self, num_samples, n_points, context=None, sample_distrib=None, extra_context=None, eps=None):
         dist = sample_distrib if sample_distrib is not None else self.sample_dist
@@ -365,7 +366,8 @@ class _DGCNNBase(nn.Module):
         if self.training:                                  # (also under no_grad: train-mode BatchNorm normalises with batch statistics)
             from . import train_embed
             return train_embed.dgcnn_embed(self, x)
-        return self._engine().embed(x)
+        from . import library_ops
+        return torch.ops.flowcompare_amd.context_embed(x, library_ops.register(self._engine()))
 
 
 class DGCNNembedder(_DGCNNBase):
@@ -482,4 +484,5 @@ class PointNet2SSGSeg(nn.Module):
         if self.training:
             from . import train_paconv
             return train_paconv.paconv_embed(self, pointcloud)
-        return self._engine().embed(pointcloud)
+        from . import library_ops
+        return torch.ops.flowcompare_amd.context_embed(pointcloud, library_ops.register(self._engine()))

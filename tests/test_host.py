@@ -116,3 +116,36 @@ def test_spline_parameter_columns_are_a_bijection_in_register_slot_order():
         assert [col(dl, pp, 8) for pp in range(25)] == [slot_col((dl & 1) * 25 + pp, dl >> 1) for pp in range(25)]
     assert [col(4, pp, 8) for pp in range(25)] == [slot_col(50 + pp, 0) for pp in range(14)] + [slot_col(50 + pp, 1) for pp in range(11)]
     assert sorted(set(range(128)) - {col(j, pp, 8) for j in range(5) for pp in range(25)}) == [125, 126, 127]
+
+
+def test_inference_entry_points_are_torch_library_ops():
+    """the forward / embedder entry points are registered as torch.library custom ops (flowcompare_amd/library_ops.py), HIP devices
+    only; their fake implementations give the output shapes (what torch.compile / export trace through); a CPU call fails loudly."""
+    from flowcompare_amd import library_ops
+    for name in ("flow_log_prob", "context_embed"):
+        assert hasattr(torch.ops.flowcompare_amd, name)
+    x = torch.empty(3, 7, 6, device="meta")
+    lp = torch.ops.flowcompare_amd.flow_log_prob(x, torch.empty(3, 9, 64, device="meta"), None, [torch.empty(3, 7, 294, device="meta")], 0)
+    assert lp.shape == (3, 7) and lp.dtype == torch.float32 and lp.device.type == "meta"
+
+    class _H:                                              # stands in for an engine handle: the fake implementation only reads its geometry
+        out_dim, is_global = 64, False
+    h = _H()
+    key = library_ops.register(h)
+    emb = torch.ops.flowcompare_amd.context_embed(torch.empty(2, 11, 6, device="meta"), key)
+    assert emb.shape == (2, 11, 64)
+    with pytest.raises(NotImplementedError):
+        torch.ops.flowcompare_amd.flow_log_prob(torch.zeros(1, 2, 6), torch.zeros(1, 2, 64), None, [], key)       # no CPU kernel exists
+    del h
+    with pytest.raises(RuntimeError, match="no live engine handle"):
+        library_ops._get(key)
+
+
+def test_data_parallel_without_a_process_group_says_how_to_launch():
+    """config['data_parallel'] (model_initialization.py:186-188: nn.DataParallel) means scene sharding with one process per GPU here; outside a
+    torch.distributed process group initialize_flow says so instead of building something that cannot shard."""
+    fx = Fixture("e2e_tiny_affine")
+    cfg = dict(fx.cfg)
+    cfg["data_parallel"] = True
+    with pytest.raises(RuntimeError, match="torch.distributed.run"):
+        fa.initialize_flow(cfg, device="cpu", mode="test")

@@ -228,3 +228,48 @@ def test_gradient_presence_mask_follows_the_other_rank():
         assert p.exitcode == 0
     for rank, seen in res:
         assert seen == [[False, False, False], [False, False, True], [False, False, True]], (rank, seen)
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import flowcompare_amd as fa
+        from flowcompare_amd import model_initialization as MI
+        fx = Fixture("e2e_tiny_affine")
+        cfg = dict(fx.cfg)
+        cfg["data_parallel"] = True
+        md = fa.initialize_flow(cfg, device="cpu", mode="test")
+        seen = {}
+
+        def fake_inner(batch, models_dict, config, eps=None):          # what the rank would hand its engine: record the shard, return a log-prob
+            seen["scenes"] = batch[0].shape[0]
+            lp = torch.full((batch[1].shape[0], batch[1].shape[1]), float(rank + 1))
+            return -lp.mean(), lp, torch.tensor(0.0)
+        real = MI.inner_loop
+        batch = (fx.t("extract_0"), fx.t("extract_1"), fx.t("extra"))   # B = 3 scenes: 2 + 1
+        import unittest.mock as mock
+        with mock.patch.object(MI, "inner_loop", side_effect=lambda *a, **k: fake_inner(*a, **k) if md.get("_in_shard") else real(*a, **k)):
+            loss, lp, _ = real(batch, md, cfg)
+        q.put((rank, bool(md.get("sharded")), seen["scenes"], float(loss), tuple(lp.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_data_parallel_config_routes_inner_loop_to_the_scene_shards():
+    """config['data_parallel']: under a process group initialize_flow marks the model dict as sharded and inner_loop takes the GLOBAL batch,
+    runs this rank's scenes (2 + 1 of 3) and returns the global loss: -(2 scenes x 1.0 + 1 scene x 2.0) / 3 per point."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=100) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True] and [r[2] for r in res] == [2, 1]
+    for _, _, _, loss, _ in res:
+        assert abs(loss - (-(2 * 1.0 + 1 * 2.0) / 3)) < 1e-6
