@@ -203,6 +203,9 @@ def training_child_env(environ):
     """The child's rendezvous: same rank / world / address, the NEXT port (the parent's store may still hold its port)."""
     env = dict(environ)
     env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 1)
+    # under torch.distributed.run the workers are CLIENTS of the agent's store (TORCHELASTIC_USE_AGENT_STORE=True) at MASTER_PORT; nobody serves
+    # the next port, so the children's rank 0 must host their store itself (first form of this leg: the child waited for a server forever)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("RANK", "0")
     env.setdefault("LOCAL_RANK", "0")
@@ -224,7 +227,7 @@ def parse_training_child(rc, stdout, timed_out=False):
         return {"error": f"training leg (child process): unreadable line ({e})"}
 
 
-def run_training_child(args, rank, world, limit_s=900.0):
+def run_training_child(args, rank, world, limit_s=600.0):
     import subprocess
     cmd, env = training_child_command(args, args.train_steps), training_child_env(os.environ)
     log(f"rank {rank}: training leg in a child process (MASTER_PORT {env['MASTER_PORT']})")

@@ -25,8 +25,9 @@ def test_training_child_command_and_rendezvous():
     assert cmd[0] == sys.executable and cmd[1].endswith("bench.py") and "--train-child" in cmd
     for flag, val in (("--gpus", "4"), ("--steps", "2"), ("--config", _Args.config), ("--batch", "20"), ("--points", "1024"), ("--ctx-points", "1250"), ("--knob", "29=1")):
         assert cmd[cmd.index(flag) + 1] == val
-    env = bench.training_child_env({"MASTER_PORT": "29500", "MASTER_ADDR": "127.0.0.1", "RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "4"})
+    env = bench.training_child_env({"MASTER_PORT": "29500", "MASTER_ADDR": "127.0.0.1", "RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "4", "TORCHELASTIC_USE_AGENT_STORE": "True"})
     assert env["MASTER_PORT"] == "29501" and env["RANK"] == "3" and env["WORLD_SIZE"] == "4"      # same ranks, the next port
+    assert "TORCHELASTIC_USE_AGENT_STORE" not in env                                               # ... whose store the children's rank 0 hosts itself
     env1 = bench.training_child_env({})
     assert env1["RANK"] == "0" and env1["WORLD_SIZE"] == "1" and env1["MASTER_ADDR"] == "127.0.0.1"
 
