@@ -17,7 +17,7 @@ struct TmpBuf {
 }  // namespace fc
 
 
-namespace fc { void one_acc_gemm_debug(const float*, const float*, const float*, float, float*, int, int, int, hipStream_t); long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; extern int g_spline_wide_dma; extern int g_spline_wide_colgroup; extern int g_linear_wide; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
+namespace fc { void one_acc_gemm_debug(const float*, const float*, const float*, float, float*, int, int, int, hipStream_t); long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; extern int g_spline_wide_dma; extern int g_spline_wide_colgroup; extern int g_linear_wide; extern int g_attn_stagger; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }
 
 extern "C" {
@@ -49,6 +49,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 24) fc::g_knn_mfma = value;          /* 1 = k-NN Gram tiles on the matrix cores (default), 0 = lane-per-candidate kernel */
     else if (key == 27) fc::g_spline_wide_dma = value;   /* developer builds: DMA pieces per phase of the wide fused spline kernel (spline_wide.hip) */
     else if (key == 29) fc::g_linear_wide = value;       /* hidden layers of the coupling MLP on the 256 x 256 one-accumulator kernel: 0 = off (default: measured no faster than the chain), 1 = for scenes of >= 2048 target points, 2 = at any size */
+    else if (key == 30) fc::g_attn_stagger = value;     /* 1 = split-fp16 attention as one 512-thread workgroup of two staggered wave groups (default), 0 = the four-wave kernel; bit-identical */
     else if (key == 28) fc::g_spline_wide_colgroup = value;   /* column-group size of its tile order (-1 = shipped) */
     else if (key == 20) fc::g_gemm_stamp = value;        /* diagnostic: in-kernel phase stamps of the LDS-DMA fused-spline launches */
     else if (key == 14) fc::g_spline_ablate = value;     /* diagnostic: 1 = fused spline epilogue without the spline evaluation, 2 = main loop only (results invalid) */
