@@ -213,6 +213,7 @@ struct Attn16Params {
     int kv_pitch;                   // row pitch of the k16 / v16 images in 16-byte chunks (DH / 4 for the packed images)
     int c16;                        // 1: rows are slices of a GEMM's limb-image output ([16 columns: hi 16 | lo' 16] tiles, GemmEpi::C16)
     float* lse = nullptr;           // optional [B * n_stride]: natural-log sum-exp of every query's scaled scores (training: the backward reuses it)
+    unsigned long long* stamps = nullptr;   // diagnostic knob 20 = 5 (attn16x2_kernel): s_memtime at the slot boundaries of workgroup (0, 0), both groups
 };
 
 // fp32 K / V columns of the projected context -> limb row images; raises *ovf on |x| >= 65504.
@@ -538,11 +539,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void a
 #define FC_SLOT_END                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0 && nst < 96) p.stamps[grp * 256 + 2 * nst] = __builtin_amdgcn_s_memtime();   \
     __builtin_amdgcn_s_barrier();                                                             \
+    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0 && nst < 96) p.stamps[grp * 256 + 2 * nst + 1] = __builtin_amdgcn_s_memtime();  \
+    ++nst;                                                                                    \
     __builtin_amdgcn_sched_barrier(0);
 
     const int tr_off = (4 * lh + ((lane & 15) >> 2)) * VP + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     const int ntiles = (p.M + 63) / 64;
+    int nst = 0;                                               // slot counter of the diagnostic stamps
 
     floatx16 s[2];                                             // scores of the tile in flight (S phase -> softmax phase)
     f16x8 ph[2][2], pl[2][2];                                  // limbs of its probabilities (softmax phase -> P V phase)
@@ -688,7 +693,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
 }
 
-int g_attn_stagger = 1;      // knob 30: 1 = the 512-thread kernel with two staggered wave groups where a scene has at least 256 queries (shipped), 0 = attn16_kernel
+extern int g_gemm_stamp;
+unsigned long long* gemm_stamp_buffer(size_t n);
+int g_attn_stagger = 0;      // knob 30: 1 = the 512-thread kernel with two staggered wave groups where a scene has at least 256 queries, 0 = attn16_kernel (shipped:
+                             // same bits, and the stagger measured no gain - 26.58 vs 26.21 ms per C2 step, profiles/r04r_attn_stamps.log has the slot timings)
 
 template <int DH>
 static void launch_attn16_dh(const Attn16Params& p, int B, hipStream_t s) {
@@ -700,13 +708,15 @@ static void launch_attn16_dh(const Attn16Params& p, int B, hipStream_t s) {
     snprintf(name, sizeof name, "void fc::attn16_kernel<%d>(fc::Attn16Params)", DH);
     // the choice depends on the SCENE's query count only (never on the batch): both kernels give the same bits anyway
     if (g_attn_stagger && p.N >= 256) {
+        Attn16Params p2 = p;
+        if (g_gemm_stamp == 5) { p2.stamps = gemm_stamp_buffer(512); FC_HIP(hipMemsetAsync(p2.stamps, 0, 512 * sizeof(unsigned long long), s)); }
         static PerDeviceOnce attr2_once;
         auto kern2 = attn16x2_kernel<DH>;
         attr2_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); return 0; });
         char name2[64];
         snprintf(name2, sizeof name2, "void fc::attn16x2_kernel<%d>(fc::Attn16Params)", DH);
         ProfScope ps2(name2, 4.0 * B * (double)p.N * (double)p.M * DH, 0.0, s);
-        hipLaunchKernelGGL(kern2, dim3((p.N + 255) / 256, B), dim3(512), lds, s, p);
+        hipLaunchKernelGGL(kern2, dim3((p.N + 255) / 256, B), dim3(512), lds, s, p2);
         FC_HIP(hipGetLastError());
         return;
     }
