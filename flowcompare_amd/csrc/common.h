@@ -293,6 +293,27 @@ void launch_linear_wide(const PackedLinear& L, const GemmEpi& e, int rows_alloc,
 bool gemm_linear_wide_on();      // knob 29 (1: for scenes of at least 2048 target points, 2: at any size)
 int gemm_linear_wide_knob();
 bool gemm_spline_wide_on();      // knob 13 = 5 (shipped): launch_gemm routes eligible EPI_SPLINE launches there
+// the same 256 x 256 main loop for the wide Linear layers of a TRAINING step (train.hip: the spline parameter layer's forward and its data
+// gradient): the point operand is an fp32 panel, split into limbs after its LDS read; C = (A W^T + bias (+ addend)) (* act'(gradu))
+constexpr int kTrainWideWExp = 11;         // weights of those layers are stored as hi + lo of w 2^11 (|w| < 32; the pack kernel raises the range flag beyond)
+struct TrainWideArgs {
+    const float* A = nullptr; int lda = 0;          // [rows_pad][lda] fp32, lda >= K_pad
+    const unsigned short* W1 = nullptr;              // [round_up(n_cols, 256)][K_pad / 16][hi 16 | lo 16], scaled by 2^kTrainWideWExp
+    const float* bias1 = nullptr;                    // [round_up(n_cols, 256)] times a_scale 2^kTrainWideWExp, or null
+    int K_pad = 0, rows_pad = 0, n_cols = 0;
+    float a_scale = kOneAccActScale;                 // scale of A when row_absmax is null
+    const float* row_absmax = nullptr;               // [rows_pad] max |A[row, :]|: per-row power-of-two scales (gradients)
+    float* C = nullptr; int ldc = 0;
+    const float* addend = nullptr;                   // [rows_pad][ldc] or null
+    const float* gradu = nullptr; int ldgu = 0, gact = 0;
+    int* ovf = nullptr;
+    double flops = 0.0;
+};
+void launch_train_wide(const TrainWideArgs& a, hipStream_t s);
+extern int g_train_wide;         // knob 31: 1 = training Linear layers with at least 1024 outputs run on it (shipped), 0 = on the fp32-A 128 x 128 loop
+// row maxima of a gradient panel, handed from the kernel that writes it (training spline backward) to the data-gradient GEMM that reads it
+float* train_rowmax_reserve(const float* tensor, int rows, hipStream_t s);
+const float* train_rowmax_take(const float* tensor, int rows, hipStream_t s);
 // staging.hip: the steps either side of the path
 void launch_fps_nd(const float* pts, int ld, int C, int64_t* idx, int B, int n, int m, float* dist_scratch, hipStream_t s);
 void launch_co_unit_sphere(const float* p0, int n0, const float* p1, int n1, int ld, float* o0, float* o1, float* inverse, int B, hipStream_t s);

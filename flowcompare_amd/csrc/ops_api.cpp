@@ -49,6 +49,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 24) fc::g_knn_mfma = value;          /* 1 = k-NN Gram tiles on the matrix cores (default), 0 = lane-per-candidate kernel */
     else if (key == 27) fc::g_spline_wide_dma = value;   /* developer builds: DMA pieces per phase of the wide fused spline kernel (spline_wide.hip) */
     else if (key == 29) fc::g_linear_wide = value;       /* hidden layers of the coupling MLP on the 256 x 256 one-accumulator kernel: 0 = off (default: measured no faster than the chain), 1 = for scenes of >= 2048 target points, 2 = at any size */
+    else if (key == 31) fc::g_train_wide = value;       /* 1 = training Linear layers with >= 1024 outputs (the spline parameter layer) on the 256 x 256 one-accumulator loop (default), 0 = on the fp32-A 128 x 128 loop, 3 = 1 with non-temporal stores of a GB-sized output (measured slower) */
     else if (key == 30) fc::g_attn_stagger = value;     /* 1 = split-fp16 attention as one 512-thread workgroup of two staggered wave groups, 0 = the four-wave kernel (default); bit-identical */
     else if (key == 28) fc::g_spline_wide_colgroup = value;   /* column-group size of its tile order (-1 = shipped) */
     else if (key == 20) fc::g_gemm_stamp = value;        /* diagnostic: in-kernel phase stamps of the LDS-DMA fused-spline launches */

@@ -58,6 +58,15 @@ struct SplineWideParams {
     int* ovf;                    // split-fp16 range flag (common.h Fp16Guard)
     // EPI 2 (plain product, fc_debug_one_acc_gemm_f32: the one-accumulator limb form by itself, for the accuracy test)
     float* C; int ldc;
+    // EPI 3 (training Linear, csrc/train.hip): the point operand is an fp32 PANEL [rows][lda] that is split into limbs after its LDS read
+    // (a k32 step of a row is 128 bytes either way), scaled by a_scale or, for gradients, per row so that the row's maximum lands in
+    // [2^13, 2^14) (row_absmax: max |a| of every row, written by the producing kernel); C = (acc / scale (+ addend)) (* act'(gradu))
+    const float* A32; int lda;
+    const float* row_absmax;
+    float a_scale;
+    const float* addend; const float* gradu; int ldgu; int gact;
+    int n_cols;                  // columns of C that exist (a multiple of 4; the last 256-column tile may be partly empty)
+    int nt_store;                // C is written with non-temporal stores
 };
 
 // column of the kernel's tile order: row kq = (c >> 2) & 3 of 16-parameter block jb = c >> 4, register r = c & 3 -> slot s = 4 jb + r
@@ -165,6 +174,34 @@ __device__ __forceinline__ void rq_spline_fwd_regs_scaled(float x, const U& u, f
     lad = inside ? ll : 0.f;
 }
 
+// eight fp32 values (k = 8 kq .. 8 kq + 7 of one point) -> the hi / lo operand fragments of the one-accumulator form, x s = hi + lo with s an
+// exact power of two; amax collects max |x s| (the caller turns it into the range flag).  Five instructions per pair of values (measured issue
+// costs on gfx950, profiles/micro/valu_rate_probe.hip: v_pk_mul_f32 6.6, v_cvt_pk_f16_f32 8.1, v_fma_mix_f32 8.4 cycles per wave; the all-mix
+// form of activations.h limb_split2s is six at 8.4 - 9.3).
+typedef float sw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sw_split2v(sw_f32x2 x, sw_f32x2 sv, unsigned& hi, unsigned& lo, float& amax) {
+    sw_f32x2 t;
+    float d0, d1;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(sv));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(t[0]), "v"(t[1]));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(d0) : "v"(t[0]), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d1) : "v"(t[1]), "v"(hi));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
+    asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(t[0]), "v"(t[1]));      // (volatile: pins the running maximum; left to hipcc the raw values of a k step are kept for one reduction tree and spill)
+}
+__device__ __forceinline__ void sw_split8(const float4& r0, const float4& r1, float sv, f16x8& hi, f16x8& lo, float& amax) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h, l;
+    unsigned a, b;
+    const sw_f32x2 s2 = {sv, sv};
+    sw_split2v(sw_f32x2{r0.x, r0.y}, s2, a, b, amax); h[0] = a; l[0] = b;
+    sw_split2v(sw_f32x2{r0.z, r0.w}, s2, a, b, amax); h[1] = a; l[1] = b;
+    sw_split2v(sw_f32x2{r1.x, r1.y}, s2, a, b, amax); h[2] = a; l[2] = b;
+    sw_split2v(sw_f32x2{r1.z, r1.w}, s2, a, b, amax); h[3] = a; l[3] = b;
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
+}
+
 constexpr int SW_LDS = 4 * 32768 + 2 * 1024;      // two stages of (256 point rows + 256 weight rows) x 128 B, two bias buffers of 256 floats
 
 // DMA pieces per LOAD segment of a k step, for the group that fetches the points (waves 0-3: P*) and the weights (waves 4-7: Q*); the
@@ -182,7 +219,8 @@ void spline_wide_kernel(const SplineWideParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, pw = wave & 3;
     const int KT = p.KT;
-    const unsigned rowbytes = (unsigned)KT * 128u;
+    constexpr bool AF32 = EPI == 3;                                      // the point operand is an fp32 panel (split into limbs in registers)
+    const unsigned rowbytes = (AF32 && grp == 0) ? (unsigned)p.lda * 4u : (unsigned)KT * 128u;      // of the operand THIS wave fetches
     const int ntiles = p.nbm * p.nbn, G = gridDim.x;
     int t = blockIdx.x;
     if (t >= ntiles) return;
@@ -216,7 +254,8 @@ void spline_wide_kernel(const SplineWideParams p) {
         poff[par] = (unsigned)r * rowbytes + cl * 16;
     }
     auto src_of = [&](int bm, int bn) -> const char* {
-        return grp == 0 ? reinterpret_cast<const char*>(p.A16) + (size_t)bm * 256 * rowbytes : reinterpret_cast<const char*>(p.W1) + (size_t)bn * 256 * rowbytes;
+        return grp == 0 ? (AF32 ? reinterpret_cast<const char*>(p.A32) : reinterpret_cast<const char*>(p.A16)) + (size_t)bm * 256 * rowbytes
+                        : reinterpret_cast<const char*>(p.W1) + (size_t)bn * 256 * rowbytes;
     };
     const int dst0 = grp * 65536 + pw * 8192;
 #define SW_DMA(SRC_, ST_, I0_, N_)                                                                                                      \
@@ -226,7 +265,7 @@ void spline_wide_kernel(const SplineWideParams p) {
                                              (lds_char*)(smc + dst0 + (ST_) * 32768 + i_ * 1024), 16, 0, 0);                            \
     }
     auto bias_dma = [&](int bn, int par) {                              // 256 floats: waves 0-3, 4 bytes per lane
-        if (grp == 0)
+        if (grp == 0 && (EPI != 3 || p.bias1))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) float*)(p.bias1 + bn * 256 + pw * 64 + lane),
                                              (__attribute__((address_space(3))) float*)(biasbuf + par * 256 + pw * 64), 4, 0, 0);
     };
@@ -240,6 +279,43 @@ void spline_wide_kernel(const SplineWideParams p) {
         abase[q] = (pw * 64 + l15) * 128 + c;
         bbase[q] = 65536 + (grp * 128 + l15) * 128 + c;
     }
+    // EPI 3: the point rows arrive as fp32 (a k32 step of a row = 32 floats = the same 128 bytes) and are turned into the limb image IN PLACE, one
+    // k step ahead of their use: lane (l15, kq) reads the eight floats k = 8 kq .. 8 kq + 7 (chunks 2 kq, 2 kq + 1) and writes their hi / lo
+    // limbs to the image's chunks; wave w converts point blocks 0, 1 of its 64 rows, wave w + 4 (the other group, same rows) blocks 2, 3
+    const int cbase = (pw * 64 + grp * 32 + l15) * 128;
+    const int cin0 = ((2 * kq) ^ xsw) * 16, cin1 = ((2 * kq + 1) ^ xsw) * 16;
+    const int cout0 = abase[0] - (pw * 64 + l15) * 128, cout1 = abase[1] - (pw * 64 + l15) * 128;
+    // EPI 3: scale of this lane's four points (point (ib, l15)) and what undoes it in the epilogue
+    float csc[2] = {1.f, 1.f}, amax = 0.f;                               // scales of the two point blocks this wave converts (of the tile whose data comes next)
+    bool bad_row = false;
+    auto row_scale = [&](int bm, int ib0, int n, float* sc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= n) break;
+            const int ib = ib0 + j;
+            if (p.row_absmax) {
+                const unsigned bits = __builtin_bit_cast(unsigned, p.row_absmax[bm * 256 + pw * 64 + ib * 16 + l15]);
+                const int e = (int)((bits >> 23) & 0xffu);                       // biased exponent of the row's maximum: 2^(e - 127) <= max < 2^(e - 126)
+                int se = e == 0 ? 127 : 267 - e;                                 // scale 2^(13 - (e - 127)): max lands in [2^13, 2^14)
+                se = se > 254 ? 254 : se;
+                bad_row |= e == 255;                                             // inf / NaN in the row: range flag
+                sc[j] = __builtin_bit_cast(float, (unsigned)se << 23);
+            } else sc[j] = p.a_scale;
+        }
+    };
+    // converts this wave's two point blocks of LDS stage `st` in place (reads before writes: one wave's LDS operations execute in order)
+    auto convert_stage = [&](int st) {
+        char* base = smc + st * 32768 + cbase;
+        const float4 a0 = *reinterpret_cast<const float4*>(base + cin0), a1 = *reinterpret_cast<const float4*>(base + cin1);
+        const float4 b0 = *reinterpret_cast<const float4*>(base + 2048 + cin0), b1 = *reinterpret_cast<const float4*>(base + 2048 + cin1);
+        f16x8 h0, l0, h1, l1;
+        sw_split8(a0, a1, csc[0], h0, l0, amax);
+        sw_split8(b0, b1, csc[1], h1, l1, amax);
+        *reinterpret_cast<f16x8*>(base + cout0) = h0;
+        *reinterpret_cast<f16x8*>(base + cout1) = l0;
+        *reinterpret_cast<f16x8*>(base + 2048 + cout0) = h1;
+        *reinterpret_cast<f16x8*>(base + 2048 + cout1) = l1;
+    };
     // this lane's share of a tile's x2 operands: dim kq of point (ib, l15) for ib = 0..3, dim 4 of point (kq, l15), and that point's log-det slot
     auto load_x = [&](int bm, int bn, float (&x)[5], float& ldj) {
         const int t128 = 2 * bn + grp, dim0 = t128 * 5;
@@ -262,8 +338,14 @@ void spline_wide_kernel(const SplineWideParams p) {
     float spl_x[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, spl_ldj = 0.f;
     if constexpr (EPI == 0) load_x(bm, bn, spl_x, spl_ldj);
     float omax = 0.f;
+    if constexpr (EPI == 3) row_scale(bm, 2 * grp, 2, csc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (AF32) {
+        convert_stage(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
     if (grp == 1) __builtin_amdgcn_s_barrier();                         // the second group runs one segment behind the first
 
     floatx4 acc[4][8];
@@ -278,9 +360,10 @@ void spline_wide_kernel(const SplineWideParams p) {
         {
             // accumulators start from the (pre-scaled) bias: register r of block jb is tile column 16 jb + 4 kq + r for every point block
             const float* bb = biasbuf + par * 256 + grp * 128 + 4 * kq;
+            const bool has_bias = EPI != 3 || p.bias1 != nullptr;
 #pragma unroll
             for (int jb = 0; jb < 8; ++jb) {
-                const float4 b4 = *reinterpret_cast<const float4*>(bb + jb * 16);
+                const float4 b4 = has_bias ? *reinterpret_cast<const float4*>(bb + jb * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int ib = 0; ib < 4; ++ib) { acc[ib][jb][0] = b4.x; acc[ib][jb][1] = b4.y; acc[ib][jb][2] = b4.z; acc[ib][jb][3] = b4.w; }
             }
@@ -297,6 +380,12 @@ void spline_wide_kernel(const SplineWideParams p) {
                     wf[jj][q] = *reinterpret_cast<const f16x8*>(smc + bbase[q] + (ST_) * 32768 + (2 * (F_) + jj) * 2048);                 \
             if (grp == 0) { if ((NP_) > 0) SW_DMA(dsrc, (ST_) ^ 1, I0P_, NP_) }                                                          \
             else { if ((NQ_) > 0) SW_DMA(dsrc, (ST_) ^ 1, I0Q_, NQ_) }                                                                   \
+            if constexpr (AF32) {                                        /* the NEXT k step's point rows (all of them issued in phases 0, 1): fp32 -> limb image in place */ \
+                if ((F_) == 3) {                                                                                                          \
+                    if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* own rows; the other group converts behind the next barrier */ \
+                    convert_stage((ST_) ^ 1);                                                                                             \
+                }                                                                                                                         \
+            }                                                                                                                             \
             if ((LAST_) && grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                                                            \
@@ -330,6 +419,7 @@ void spline_wide_kernel(const SplineWideParams p) {
             if (lastk && has_next) {                                    // the stream runs on into the next tile: its bias and x2 / log-det operands too
                 bias_dma(nbn, par ^ 1);
                 if constexpr (EPI == 0) load_x(nbm, nbn, nx, nldj);
+                if constexpr (EPI == 3) row_scale(nbm, 2 * grp, 2, csc);      // (this tile's remaining conversion is the next tile's first k step)
             }
             SW_STEP(1)
         }
@@ -344,6 +434,37 @@ void spline_wide_kernel(const SplineWideParams p) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (EPI == 3) {
+            // ---- training Linear: C = (acc / scale + addend) * act'(gradu); a lane holds columns 16 jb + 4 kq + 0..3 of point (ib, l15)
+            float asc[4];
+            row_scale(bm, 0, 4, asc);
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const size_t row = (size_t)(bm * 256 + pw * 64 + ib * 16 + l15);
+                const int col0 = bn * 256 + grp * 128 + 4 * kq;
+                // (a per-row scale is an exact power of two 2^(se - 127): its inverse is the exponent 254 - se)
+                const float sc = p.row_absmax ? __builtin_bit_cast(float, (254u - (__builtin_bit_cast(unsigned, asc[ib]) >> 23)) << 23) * p.out_scale : p.out_scale;
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb) {
+                    const int col = col0 + jb * 16;
+                    if (col < p.n_cols) {
+                        float4 v = make_float4(acc[ib][jb][0] * sc, acc[ib][jb][1] * sc, acc[ib][jb][2] * sc, acc[ib][jb][3] * sc);
+                        if (p.addend) {
+                            const float4 a = *reinterpret_cast<const float4*>(p.addend + row * p.ldc + col);
+                            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                        }
+                        if (p.gradu) {
+                            const float4 u = *reinterpret_cast<const float4*>(p.gradu + row * p.ldgu + col);
+                            v.x *= fc_gelu_grad(u.x); v.y *= fc_gelu_grad(u.y); v.z *= fc_gelu_grad(u.z); v.w *= fc_gelu_grad(u.w);      // (GELU only: launch_train_wide checks)
+                        }
+                        typedef float sw_f4 __attribute__((ext_vector_type(4)));
+                        const sw_f4 v4 = {v.x, v.y, v.z, v.w};
+                        if (p.nt_store) __builtin_nontemporal_store(v4, reinterpret_cast<sw_f4*>(p.C + row * p.ldc + col));      // (a GB-sized panel streams out past the L2)
+                        else *reinterpret_cast<sw_f4*>(p.C + row * p.ldc + col) = v4;
+                    }
+                }
+            }
+        } else
         if constexpr (EPI == 2) {
             const float os = p.out_scale;
 #pragma unroll
@@ -485,6 +606,7 @@ void spline_wide_kernel(const SplineWideParams p) {
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
     if constexpr (EPI == 1) { if (!(omax < 65504.0f) && p.ovf) atomicOr(p.ovf, 1); }      // (also on a NaN)
+    if constexpr (EPI == 3) { if (p.ovf && (bad_row || !(amax < 65504.0f))) atomicOr(p.ovf, 1); }      // (amax: of the scaled values; also on a NaN)
 #undef SW_DMA
 #undef SW_PHASE
 #undef SW_STEP
@@ -663,6 +785,49 @@ void one_acc_gemm_debug(const float* x, const float* W, const float* bias, float
     FC_HIP(hipGetLastError());
     FC_HIP(hipMemcpyAsync(out, cp.f(), (size_t)rows * N * 4, hipMemcpyDeviceToDevice, s));
     FC_HIP(hipStreamSynchronize(s));
+}
+
+}  // namespace fc
+
+namespace fc {
+
+// ---------------------------------------------------------------- EPI 3: the wide Linear layers of a training step (train.hip)
+int g_train_wide = 1;
+
+void launch_train_wide(const TrainWideArgs& a, hipStream_t s) {
+    if (!a.A || !a.W1 || !a.C || a.K_pad < 64 || a.K_pad % 64 != 0 || a.rows_pad < 256 || a.rows_pad % 256 != 0 || a.n_cols < 4 || a.n_cols % 4 != 0 ||
+        a.lda < a.K_pad || a.lda % 4 != 0 || a.ldc < a.n_cols || a.ldc % 4 != 0 || (a.gradu && (a.ldgu < a.n_cols || a.ldgu % 4 != 0)) ||
+        (((uintptr_t)a.A | (uintptr_t)a.C | (uintptr_t)a.addend | (uintptr_t)a.gradu) & 15) || (a.row_absmax && a.bias1) || (a.gradu && a.gact != FC_ACT_GELU))
+        throw Error(FC_ERR_INVALID, "launch_train_wide: K % 64 == 0, rows % 256 == 0, 16-byte aligned panels with pitches in multiples of 4, no bias beside per-row scales, GELU as the only activation gradient");
+    SplineWideParams p{};
+    p.A32 = a.A; p.lda = a.lda; p.W1 = a.W1; p.bias1 = a.bias1;
+    p.KT = a.K_pad / 32;
+    p.nbm = a.rows_pad / 256;
+    p.nbn = (a.n_cols + 255) / 256;
+    p.ntile128 = (a.n_cols + 127) / 128;
+    p.col_group = p.nbm % 8 == 0 ? (p.nbn > 5 ? 5 : p.nbn) : 0;
+    p.row_absmax = a.row_absmax;
+    p.a_scale = a.a_scale;
+    p.out_scale = a.row_absmax ? ldexpf(1.f, -kTrainWideWExp) : 1.0f / (a.a_scale * ldexpf(1.f, kTrainWideWExp));
+    p.C = a.C; p.ldc = a.ldc; p.addend = a.addend; p.gradu = a.gradu; p.ldgu = a.ldgu; p.gact = a.gact; p.n_cols = a.n_cols;
+    p.ovf = a.ovf;
+    // knob 31 = 3: a C panel of 256 MB or more streams out with non-temporal stores (measured on the C2 training step, same box: 1116 against 1092 ms
+    // with ordinary stores, profiles/r04w_train_*.json -- not shipped)
+    p.nt_store = g_train_wide == 3 && (size_t)a.rows_pad * a.n_cols * 4 >= ((size_t)256 << 20);
+    static PerDeviceOnce attr_once, slots_once;
+    auto kern = spline_wide_kernel<3, 4, 4, 0, 0, 2, 3, 3, 0>;
+    attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS)); return 0; });
+    const int slots = slots_once.run([](int dev) {
+        int cus = 0;
+        FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int n = cus & ~7;
+        return n < 8 ? 8 : n;
+    });
+    int grid = p.nbm * p.nbn;
+    if (grid > slots) grid = slots;
+    ProfScope ps("void fc::spline_wide_kernel<3, 4, 4, 0, 0, 2, 3, 3, 0>(fc::SplineWideParams)", a.flops, 0.0, s);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), SW_LDS, s, p);
+    FC_HIP(hipGetLastError());
 }
 
 }  // namespace fc

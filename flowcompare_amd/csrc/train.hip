@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "activations.h"
 #include "common.h"
@@ -30,6 +31,10 @@ struct TrainLinearLayout {
     int nseg, seg[3], seg_pad[3];          // input panels: true and padded widths
     int K, K_pad, k_alloc;                 // sums; rows of the packed W^T
     size_t off_W, off_W2, off_bias, off_WT, off_WT2, bytes;
+    // wide layers (one input panel, at least 1024 outputs, K and N multiples of 64: the spline parameter layer): one-accumulator images of
+    // W and W^T for the 256 x 256 loop of spline_wide.hip (EPI 3) and the bias pre-scaled for it
+    int wide, n256, k256;
+    size_t off_W1, off_bias1, off_WT1;
 };
 
 static TrainLinearLayout train_layout(int N, const int32_t* seg, int nseg) {
@@ -50,6 +55,13 @@ static TrainLinearLayout train_layout(int N, const int32_t* seg, int nseg) {
     L.off_bias = take((size_t)L.n_alloc * 4);
     L.off_WT = take((size_t)L.k_alloc * L.N_pad * 4);
     L.off_WT2 = take((size_t)L.k_alloc * L.N_pad * 4);
+    L.wide = nseg == 1 && L.N_pad >= 1024 && L.N_pad % 64 == 0 && L.K_pad % 64 == 0;
+    L.n256 = round_up(L.N_pad, 256); L.k256 = round_up(L.K_pad, 256);
+    if (L.wide) {
+        L.off_W1 = take((size_t)L.n256 * L.K_pad * 4);             // [n256][K_pad/16][hi 16 | lo 16] halfs of w 2^kTrainWideWExp
+        L.off_bias1 = take((size_t)L.n256 * 4);
+        L.off_WT1 = take((size_t)L.k256 * L.N_pad * 4);            // [k256][N_pad/16][hi 16 | lo 16]
+    }
     L.bytes = o;
     return L;
 }
@@ -100,6 +112,33 @@ __global__ void train_pack_kernel(const float* __restrict__ W, const float* __re
     }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)d.n_alloc; i += stride)
         bp[i] = (bias && (int)i < d.N) ? bias[i] : 0.f;
+    if (d.wide) {
+        // one-accumulator images (spline_wide.hip): w 2^e = hi + lo with lo = rn16(w 2^e - hi) unscaled; one segment, so padded k = true k
+        unsigned short* W1 = (unsigned short*)(pack + d.off_W1);
+        unsigned short* WT1 = (unsigned short*)(pack + d.off_WT1);
+        float* b1 = (float*)(pack + d.off_bias1);
+        const float ws = (float)(1 << kTrainWideWExp);
+        auto put = [&](unsigned short* image, size_t row, int kt16, int k, float x) {
+            const float xs = x * ws;
+            if (x != 0.f && !(fabsf(xs) < 65504.0f) && ovf) atomicOr(ovf, 1);
+            const _Float16 h = (_Float16)xs;
+            const _Float16 l = (_Float16)(xs - (float)h);
+            unsigned short* dst = image + (row * kt16 + (k >> 4)) * 32 + (k & 15);
+            dst[0] = __builtin_bit_cast(unsigned short, h);
+            dst[16] = __builtin_bit_cast(unsigned short, l);
+        };
+        const size_t n1 = (size_t)d.n256 * d.K_pad, n2 = (size_t)d.k256 * d.N_pad;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) {
+            const int n = (int)(i / d.K_pad), k = (int)(i % d.K_pad);
+            put(W1, n, d.K_pad >> 4, k, (n < d.N && k < d.K) ? W[(size_t)n * d.K + k] : 0.f);
+        }
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+            const int k = (int)(i / d.N_pad), n = (int)(i % d.N_pad);
+            put(WT1, k, d.N_pad >> 4, n, (n < d.N && k < d.K) ? W[(size_t)n * d.K + k] : 0.f);
+        }
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)d.n256; i += stride)
+            b1[i] = (bias && (int)i < d.N) ? bias[i] * (kOneAccActScale * ws) : 0.f;
+    }
 }
 
 // ---------------------------------------------------------------- activations (models/nets.py:21-29; GELU = exact erf form)
@@ -492,6 +531,46 @@ static PackedLinear packed_transposed(const TrainLinearLayout& L, const void* pa
     return P;
 }
 
+// ---------------------------------------------------------------- row maxima of a gradient panel (producer -> data-gradient GEMM)
+// The training spline backward holds a whole row of d(parameters) in LDS when it writes it, so it also writes max |row|; the data gradient of
+// the parameter layer (the next launch that reads the panel, same stream) scales every row by an exact power of two with it before the
+// limb split (spline_wide.hip EPI 3).  One entry per device; taking it consumes it (a panel that reached the GEMM by another route finds none
+// and runs on the fp32-A loop).
+namespace {
+struct RowMaxSlot { float* buf = nullptr; int cap = 0; const float* tensor = nullptr; int rows = 0; hipStream_t s = nullptr; };
+std::mutex g_rowmax_mu;
+RowMaxSlot g_rowmax[16];
+}
+float* train_rowmax_reserve(const float* tensor, int rows, hipStream_t s) {
+    int dev = 0;
+    FC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(g_rowmax_mu);
+    RowMaxSlot& r = g_rowmax[dev];
+    if (r.cap < rows) {
+        if (r.buf) { FC_HIP(hipStreamSynchronize(r.s)); FC_HIP(hipFree(r.buf)); r.buf = nullptr; r.cap = 0; }
+        FC_HIP(hipMalloc((void**)&r.buf, (size_t)rows * 4));
+        r.cap = rows;
+    }
+    r.tensor = tensor; r.rows = rows; r.s = s;
+    return r.buf;
+}
+const float* train_rowmax_take(const float* tensor, int rows, hipStream_t s) {
+    int dev = 0;
+    FC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(g_rowmax_mu);
+    RowMaxSlot& r = g_rowmax[dev];
+    if (!r.buf || r.tensor != tensor || r.rows < rows || r.s != s) return nullptr;
+    r.tensor = nullptr;
+    return r.buf;
+}
+
+// the wide layers on the 256 x 256 one-accumulator loop (forward: constant activation scale; data gradient: per-row scales)
+static bool train_wide_fwd_ok(const TrainLinearLayout& L, int rows_pad, const int32_t* ovf, const float* residual) {
+    return g_train_wide && L.wide && ovf && !residual && rows_pad % 256 == 0 && gemm_fp16_enabled();
+}
+
 static void check_panel(const void* p, int ld, int width_pad, const char* what) {
     if (!p || ld < width_pad || ld % 4 != 0 || ((uintptr_t)p & 15)) throw Error(FC_ERR_INVALID, std::string("training Linear: bad panel for ") + what);
 }
@@ -513,7 +592,8 @@ int fc_train_linear_pack_f32(const float* W, const float* bias, int32_t N, const
     const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
     if (!W || !pack || pack_bytes < L.bytes || ((uintptr_t)pack & 255)) throw Error(FC_ERR_INVALID, "fc_train_linear_pack_f32: bad argument (pack must be 256-byte aligned, fc_train_linear_pack_bytes long)");
     hipStream_t s = (hipStream_t)stream;
-    const size_t n = std::max((size_t)L.n_alloc * L.K_pad, (size_t)L.k_alloc * L.N_pad);
+    size_t n = std::max((size_t)L.n_alloc * L.K_pad, (size_t)L.k_alloc * L.N_pad);
+    if (L.wide) n = std::max(n, std::max((size_t)L.n256 * L.K_pad, (size_t)L.k256 * L.N_pad));
     ProfScope ps("fc::train_pack_kernel", 0.0, (double)n * 16.0, s);
     hipLaunchKernelGGL(train_pack_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, W, bias, L, (char*)pack, (int*)ovf);
     FC_HIP(hipGetLastError());
@@ -529,6 +609,14 @@ int fc_train_linear_fwd_f32(const void* pack, int32_t N, const int32_t* seg_widt
     for (int i = 0; i < L.nseg; ++i) { check_panel(x[i], ldx[i], L.seg_pad[i], "x"); a[i] = ASeg{x[i], ldx[i]}; }
     check_panel(u, ldu, L.N_pad, "u");
     if (residual) check_panel(residual, ldr, L.N_pad, "residual");
+    if (train_wide_fwd_ok(L, rows_pad, ovf, residual)) {
+        TrainWideArgs w;
+        w.A = x[0]; w.lda = ldx[0]; w.W1 = (const unsigned short*)((const char*)pack + L.off_W1); w.bias1 = (const float*)((const char*)pack + L.off_bias1);
+        w.K_pad = L.K_pad; w.rows_pad = rows_pad; w.n_cols = L.N_pad; w.C = u; w.ldc = ldu; w.ovf = (int*)ovf;
+        w.flops = 2.0 * rows_pad * (double)L.N * (double)L.K;
+        launch_train_wide(w, (hipStream_t)stream);
+        return FC_OK;
+    }
     const PackedLinear P = packed_forward(L, pack, ovf != nullptr);
     GemmEpi e{};
     e.C = u; e.ldc = ldu; e.residual = residual; e.ldr = ldr; e.rows_valid = rows_pad;
@@ -566,6 +654,16 @@ int fc_train_linear_dgrad_f32(const void* pack, int32_t N, const int32_t* seg_wi
     if (!pack || rows_pad < 1 || rows_pad % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "fc_train_linear_dgrad_f32: bad argument (rows_pad must be a multiple of 256)");
     check_panel(du, ldu, L.N_pad, "du");
     check_panel(dx, lddx, L.K_pad, "dx");
+    if (g_train_wide && L.wide && ovf && rows_pad % 256 == 0 && gemm_fp16_enabled()) {
+        if (const float* rmax = train_rowmax_take(du, rows_pad, (hipStream_t)stream)) {
+            TrainWideArgs w;
+            w.A = du; w.lda = ldu; w.W1 = (const unsigned short*)((const char*)pack + L.off_WT1); w.K_pad = L.N_pad; w.rows_pad = rows_pad; w.n_cols = L.K_pad;
+            w.row_absmax = rmax; w.C = dx; w.ldc = lddx; w.ovf = (int*)ovf;
+            w.flops = 2.0 * rows_pad * (double)L.N * (double)L.K;
+            launch_train_wide(w, (hipStream_t)stream);
+            return FC_OK;
+        }
+    }
     const PackedLinear P = packed_transposed(L, pack, ovf != nullptr);
     ASeg a{du, ldu};
     GemmEpi e{};
@@ -589,6 +687,16 @@ int fc_train_linear_dgrad_act_f32(const void* pack, int32_t N, const int32_t* se
     check_panel(dx, lddx, L.K_pad, "dx");
     check_panel(u_prev, lddx, L.K_pad, "u_prev");
     if (addend) check_panel(addend, lddx, L.K_pad, "addend");
+    if (g_train_wide && L.wide && ovf && rows_pad % 256 == 0 && act == FC_ACT_GELU && gemm_fp16_enabled()) {
+        if (const float* rmax = train_rowmax_take(du, rows_pad, (hipStream_t)stream)) {
+            TrainWideArgs w;
+            w.A = du; w.lda = ldu; w.W1 = (const unsigned short*)((const char*)pack + L.off_WT1); w.K_pad = L.N_pad; w.rows_pad = rows_pad; w.n_cols = L.K_pad;
+            w.row_absmax = rmax; w.C = dx; w.ldc = lddx; w.addend = addend; w.gradu = u_prev; w.ldgu = lddx; w.gact = act; w.ovf = (int*)ovf;
+            w.flops = 2.0 * rows_pad * (double)L.N * (double)L.K;
+            launch_train_wide(w, (hipStream_t)stream);
+            return FC_OK;
+        }
+    }
     const PackedLinear P = packed_transposed(L, pack, ovf != nullptr);
     ASeg a{du, ldu};
     GemmEpi e{};

@@ -148,7 +148,7 @@ template <int K>
 __global__ __launch_bounds__(256) void spline_train_bwd_kernel(const float* __restrict__ x2, int ldx, const float* __restrict__ params, int ldp,
                                                                const float* __restrict__ dy2, int lddy, const float* __restrict__ dldj,
                                                                float* __restrict__ dx2, int lddx, float* __restrict__ dparams, int lddp, int d2,
-                                                               int d2_pad, int np_pad) {
+                                                               int d2_pad, int np_pad, float* __restrict__ rowmax) {
     extern __shared__ float sp[];                        // logits in, their gradients out (in place): [round_up(d2 (3K+1), 32)]
     const size_t row = blockIdx.x;
     const int np = d2 * (3 * K + 1), np4 = (np + 3) >> 2;
@@ -170,7 +170,21 @@ __global__ __launch_bounds__(256) void spline_train_bwd_kernel(const float* __re
     for (int c = np + threadIdx.x; c < np_pad; c += 256) sp[c] = 0.f;
     __syncthreads();
     float4* dst = reinterpret_cast<float4*>(dparams + row * lddp);
-    for (int i = threadIdx.x; i < (np_pad >> 2); i += 256) dst[i] = reinterpret_cast<const float4*>(sp)[i];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < (np_pad >> 2); i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(sp)[i];
+        dst[i] = v;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) m = INFINITY;      // (fmaxf drops a NaN: the consumer must see it)
+    }
+    if (rowmax) {
+        // max |row| for the data-gradient GEMM of the parameter layer (train.hip: train_rowmax_reserve / _take)
+        __shared__ float red[4];
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) rowmax[row] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
 }
 
 // ---------------------------------------------------------------- LayerNorm: one wave per row
@@ -509,11 +523,15 @@ static void spline_fwd_k(const float* x2, int ldx, const float* params, int ldp,
 template <int K>
 static void spline_bwd_k(const float* x2, int ldx, const float* params, int ldp, const float* dy2, int lddy, const float* dldj, float* dx2, int lddx,
                          float* dparams, int lddp, int rows, int d2, hipStream_t s) {
+    // rows beyond `rows` of the row-maximum buffer (the GEMM reads a multiple of 256) are zero: scale 1 on zero rows
+    const int rows_pad = round_up(rows, ROW_PAD);
+    float* rowmax = lddp % 64 == 0 ? train_rowmax_reserve(dparams, rows_pad, s) : nullptr;
+    if (rowmax && rows_pad > rows) FC_HIP(hipMemsetAsync(rowmax + rows, 0, (size_t)(rows_pad - rows) * 4, s));
     ProfScope ps("fc::spline_train_bwd_kernel", 0.0, (double)rows * d2 * (6 * K + 5) * 4.0, s);
     const size_t lds = (size_t)round_up(d2 * (3 * K + 1), 32) * sizeof(float);
     if (lds > 60 * 1024) throw Error(FC_ERR_UNSUPPORTED, "training spline: more than 15360 logits per point");
     hipLaunchKernelGGL(spline_train_bwd_kernel<K>, dim3(rows), dim3(256), lds, s, x2, ldx, params, ldp, dy2, lddy, dldj, dx2, lddx, dparams, lddp, d2,
-                       round_up(d2, 32), round_up(d2 * (3 * K + 1), 32));
+                       round_up(d2, 32), round_up(d2 * (3 * K + 1), 32), rowmax);
     FC_HIP(hipGetLastError());
 }
 

@@ -26,7 +26,11 @@ from . import modules as M
 from . import train_ops as T
 
 LOG_2PI = math.log(2.0 * math.pi)
-ACTIVATION_BUDGET_BYTES = None      # None: 70 % of the HBM available at call time; 0: checkpoint every layer (flow_log_prob)
+ACTIVATION_BUDGET_BYTES = None      # None: ACTIVATION_BUDGET_FRACTION of the HBM available at call time; 0: checkpoint every layer (flow_log_prob)
+# Round 4: 0.85 (was 0.70).  On the C2 training step (16 x 4096 points, 115 layers, MI355X 288 GB) 0.70 keeps 75 layers and recomputes 40 in backward
+# (peak 208.6 GiB); 0.82 -> peak 240.8 GiB, -31 ms; 0.88 -> 255.7 GiB, -62 ms per step (profiles/r04w_train_*.json, same box).  0.85 leaves ~20 GiB of
+# the 268 GiB for the allocator's slack, RCCL buffers and the transient gradient panels of the layer in flight.
+ACTIVATION_BUDGET_FRACTION = float(os.environ.get("FC_TRAIN_BUDGET_FRACTION", "0.85"))
 
 
 def _attention_block(pre, h_panel, h_width, ctx_k, ctx_v, rows, B, N, Mctx):
@@ -133,7 +137,7 @@ def _actnorm_data_init(an, parts, rows):
 def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, checkpoint=True, activation_budget_bytes=None):
     """log p(x | context) [B, N] with autograd through HIP kernels.  Arguments as Flow.log_prob (modules.py); `eps` pins the
     augmenter noise; `checkpoint` recomputes a layer's forward during backward for the layers whose saved activations do not fit
-    `activation_budget_bytes` (default: 70 % of the HBM that is free at call time; 0 = checkpoint every layer).
+    `activation_budget_bytes` (default: ACTIVATION_BUDGET_FRACTION = 85 % of the HBM that is free at call time; 0 = checkpoint every layer).
     Call inside train_ops.step_guard() to run the split-fp16 loops with the range flag."""
     cfg = flow._config
     act = act or cfg["coupling_block_nonlinearity"]
@@ -270,7 +274,7 @@ def flow_log_prob(flow, x, context, extra_context=None, eps=None, act=None, chec
         if activation_budget_bytes is None:
             free, _total = torch.cuda.mem_get_info(x.device)
             reusable = torch.cuda.memory_reserved(x.device) - torch.cuda.memory_allocated(x.device)      # cached by the allocator, free to us
-            activation_budget_bytes = int(0.70 * (free + reusable))
+            activation_budget_bytes = int(ACTIVATION_BUDGET_FRACTION * (free + reusable))
         budget = int(activation_budget_bytes)
     # which ActNorm layers still wait for their first-batch statistics: ONE device read for the whole stack (a per-layer .item() is a
     # stream synchronisation per layer, which keeps the host from running ahead of the GPU)

@@ -207,6 +207,57 @@ def test_spline_forward_and_backward_match_oracle_autograd(K, d2, rows, spread):
     assert yp[:, d2:].abs().sum().item() == 0.0
 
 
+@pytest.mark.parametrize("rows,grad_scale", [(700, 1.0), (1000, 1e-5), (300, 300.0)])
+def test_spline_parameter_layer_on_the_wide_loop_matches_fp64_and_the_fp32a_loop(rows, grad_scale):
+    """Round 4: in a training step the spline parameter layer (512 -> 3750, models/spline_coupling.py:187-210 behind models/nets.py:19-30) runs its
+    forward and its data gradient on the 256 x 256 one-accumulator loop (csrc/spline_wide.hip EPI 3; csrc/train.hip routes layers with at
+    least 1024 outputs): activations are split into limbs after their LDS read at a constant scale, the gradient panel at one exact
+    power-of-two scale PER ROW taken from the row maxima the spline backward writes beside it.  Coupling net + spline + backward against
+    fp64 autograd through the pinned oracle, no worse than the fp32-A loop (debug knob 31 = 0) -- at gradient magnitudes of a loss that is
+    a mean over 65 536 points (1e-5), of order one, and large (300)."""
+    from flowcompare_amd import engine
+    L = engine.lib()
+    K, d1, d2 = 8, 150, 150
+    torch.manual_seed(11)
+    mlp = M.MLP(d1 + 64, [512, 512], d2 * (3 * K + 1)).to(DEV)
+    with torch.no_grad():
+        mlp.out_layer.weight.mul_(0.5)
+    g = torch.Generator().manual_seed(rows)
+    x1, c = torch.randn(rows, d1, generator=g), torch.randn(rows, 64, generator=g)
+    x2 = torch.rand(rows, d2, generator=g) * 7 - 3.5
+    gy, gl = torch.randn(rows, d2, generator=g) * grad_scale, torch.randn(rows, generator=g) * grad_scale
+
+    sd = {("m." + k): v.detach().cpu().double().requires_grad_(True) for k, v in mlp.state_dict().items()}
+    x1o, co, x2o = x1.double().requires_grad_(True), c.double().requires_grad_(True), x2.double().requires_grad_(True)
+    po = O.mlp(sd, "m", torch.cat((x1o, co), -1), O._act("GELU")).reshape(rows, d2, 3 * K + 1)
+    yo, lado = O.rq_spline(x2o, po[..., :K], po[..., K:2 * K], po[..., 2 * K:])
+    ((yo * gy.double()).sum() + (lado.sum(-1) * gl.double()).sum()).backward()
+
+    def run(wide):
+        assert L.fc_debug_set(31, 1 if wide else 0) == 0
+        mlp.zero_grad()
+        a, b, xx = x1.to(DEV).requires_grad_(True), c.to(DEV).requires_grad_(True), x2.to(DEV).requires_grad_(True)
+        with T.step_guard(device=DEV) as guard:
+            pp = T.mlp_panels(mlp, [T.to_panel(a), T.to_panel(b)], [d1, 64], rows, "GELU")
+            yp, ldj = T.rq_spline(T.to_panel(xx), pp, rows, d2, K)
+            ((T.from_panel(yp, rows, d2) * gy.to(DEV)).sum() + (ldj[:rows] * gl.to(DEV)).sum()).backward()
+            assert not guard.overflowed()
+        errs = dict(y=_rel(T.from_panel(yp, rows, d2).detach(), yo.detach()), ldj=_rel(ldj[:rows].detach(), lado.sum(-1).detach()),
+                    dx1=_rel(a.grad, x1o.grad, floor=1e-2 * grad_scale), dc=_rel(b.grad, co.grad, floor=1e-2 * grad_scale),
+                    dx2=_rel(xx.grad, x2o.grad, floor=1e-2 * grad_scale))
+        for k, q in mlp.named_parameters():
+            errs["d" + k] = _rel(q.grad, sd["m." + k].grad, floor=1e-2 * grad_scale)
+        return errs
+    try:
+        wide, base = run(True), run(False)
+    finally:
+        L.fc_debug_set(31, 1)
+    print(f"rows {rows} gradient scale {grad_scale}: wide loop " + " ".join(f"{k} {v:.1e}" for k, v in wide.items()))
+    print(f"{'':>{len(str(rows)) + len(str(grad_scale)) + 22}}fp32-A loop " + " ".join(f"{k} {v:.1e}" for k, v in base.items()))
+    for k in wide:
+        assert wide[k] < 2.0 * base[k] + 2e-6, (k, wide[k], base[k])
+
+
 @pytest.mark.parametrize("rows,width", [(300, 256), (1000, 8), (5, 100)])
 def test_layernorm_forward_and_backward_match_fp64(rows, width):
     g = torch.Generator().manual_seed(rows)
