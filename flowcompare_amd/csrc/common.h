@@ -337,7 +337,7 @@ void launch_ldj_reduce(const float* part, int ntiles, size_t pitch, float* logpr
 void launch_expm_coupling(const float* params, int ldp, float* xbuf, int ldx, int x2_col0, int d2, const float* scal4, float* logprob,
                           int rows, int inverse, hipStream_t s);
 void launch_spline_flat(const float* x, const float* params, float* y, float* lad, int64_t n, int K, int inverse, hipStream_t s);
-void launch_knn(const float* f, int ldf, int C, int32_t* idx, int B, int M, int m_stride_rows, int k, hipStream_t s);
+void launch_knn(const float* f, int ldf, int C, int32_t* idx, int B, int M, int m_stride_rows, int k, hipStream_t s, const int32_t* warm = nullptr);
 void launch_gather_max(const float* uv, int lduv, int c_out, const int32_t* idx, int k, float* out, int ldo, int out_col0,
                        int B, int M, int m_stride_rows, hipStream_t s);
 void launch_pool_max_mean(const float* t, int ldt, int width, float* out, int ldo, int B, int M, int m_stride_rows, hipStream_t s);

@@ -123,7 +123,7 @@ static void dgcnn_forward(fc_dgcnn& e, const float* pts, float* out, int B, int 
     for (int l = 0; l < 4; ++l) {
         const float* f = l == 0 ? w.pts : w.cat + e.lvl_col[l - 1];
         const int ldf = l == 0 ? 32 : 512;
-        launch_knn(f, ldf, e.lvl_cin[l], w.idx, B, M, M, e.k, s);
+        launch_knn(f, ldf, e.lvl_cin[l], w.idx, B, M, M, e.k, s, l > 0 ? w.idx : nullptr);      // (levels 1-3: warm start from the previous level's sets, in place)
         GemmEpi g{};
         g.C = w.uv; g.ldc = 512;
         ASeg a{f, ldf};

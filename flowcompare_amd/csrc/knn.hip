@@ -194,10 +194,11 @@ constexpr int KM_TC = 64;       // candidates per LDS block
 
 template <int CP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void knn_mfma_kernel(const float* __restrict__ f, int ldf, int C, int32_t* __restrict__ idx_out, int M, int m_stride,
-                                                       int k) {
+                                                       int k, const int32_t* __restrict__ warm) {
     extern __shared__ float smem[];
     constexpr int LDC = CP + 4, H = CP / 2, NLD = (KM_TC * CP / 4 + 255) / 256;
     float* s_qxx = smem + 2 * KM_TC * LDC;                        // [4 waves][32]
+    float* s_tau = s_qxx + 128;                                   // [4 waves][32]: warm-start thresholds
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int b = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
     const float* fb = f + (size_t)b * m_stride * ldf;
@@ -221,6 +222,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         nrm += __shfl_xor(nrm, 32);
         if (lh == 0) s_qxx[wave * 32 + li] = nrm;
+        // ---- warm start (round 4): `warm` holds k neighbours of every query from the PREVIOUS DGCNN level (models/pytorch_gcn.py:43-60: the four
+        // edge convolutions search the same cloud in successive feature spaces).  Any k distinct candidates bound the k-th best from below, so
+        // the stream starts with tau0 = min_j pd(query, warm_j) instead of -inf and the ~k ln(M / k) insertions that only serve to raise the
+        // threshold never happen (the previous level's neighbours are mostly near in this level's space too).  The selection stays EXACT:
+        // tau0 is lowered by a bound on the rounding difference between this scalar fmaf chain and the MFMA's sums, every candidate above it
+        // goes through the same sorted insertion in the same order, and tau only ever rises.  A set that holds an index twice (e.g. through the
+        // "open slots get the query itself" rule below), an index outside the cloud or a non-finite value gives no bound: tau0 = -inf, the
+        // plain stream.  Distinctness is checked for real (a wave looks at its 32 sets one after the other, entry j on lane j, against the
+        // entries 1 .. k / 2 places further round the set: every unordered pair once).
+        float tau0 = -INFINITY;
+        if (warm) {
+            unsigned dup_mask = 0;                                     // bit q: the set of this wave's query q repeats an index
+            for (int q = 0; q < 32; ++q) {
+                int qq = q0 + q;
+                qq = qq < M ? qq : M - 1;
+                const int mine = lane < k ? warm[((size_t)b * M + qq) * k + lane] : -1 - lane;
+                bool dup = false;
+                for (int d = 1; d <= k / 2; ++d) {
+                    int o = lane + d;
+                    o = o >= k ? o - k : o;
+                    dup |= lane < k && __shfl(mine, o, 64) == mine;
+                }
+                dup_mask |= __ballot(dup) ? (1u << q) : 0u;
+            }
+            const int32_t* wl = warm + ((size_t)b * M + qi) * k;
+            float tmin = INFINITY, cmax = 0.f;
+            bool bad = ((dup_mask >> li) & 1u) != 0;
+            for (int j = 0; j < k; ++j) {
+                int ci = wl[j];
+                bad |= ci < 0 || ci >= M;
+                ci = ci < 0 ? 0 : (ci >= M ? M - 1 : ci);
+                const float* row = fb + (size_t)ci * ldf + lh * H;
+                float dot = 0.f, cx = 0.f;
+#pragma unroll
+                for (int u = 0; u < H; u += 4) {
+                    float4 v = *reinterpret_cast<const float4*>(row + u);
+                    if (CP != C) {
+                        const int c0 = lh * H + u;
+                        v.x = c0 < C ? v.x : 0.f; v.y = c0 + 1 < C ? v.y : 0.f; v.z = c0 + 2 < C ? v.z : 0.f; v.w = c0 + 3 < C ? v.w : 0.f;
+                    }
+                    dot = fmaf(aq[u], v.x, dot); dot = fmaf(aq[u + 1], v.y, dot); dot = fmaf(aq[u + 2], v.z, dot); dot = fmaf(aq[u + 3], v.w, dot);
+                    cx = fmaf(v.x, v.x, cx); cx = fmaf(v.y, v.y, cx); cx = fmaf(v.z, v.z, cx); cx = fmaf(v.w, v.w, cx);
+                }
+                dot += __shfl_xor(dot, 32);
+                cx += __shfl_xor(cx, 32);
+                const float pd = fmaf(2.0f, dot, -cx) - nrm;
+                bad |= !(pd == pd);
+                tmin = fminf(tmin, pd);
+                cmax = fmaxf(cmax, cx);
+            }
+            // |2 x.y computed two ways| differs by at most ~2 C eps |x| |y| <= C eps (|x|^2 + |y|^2); 2^-21 = 4 eps covers the two subtractions as well
+            tau0 = tmin - (float)CP * 4.76837158e-7f * (nrm + cmax + fabsf(tmin));
+            if (bad || !(tau0 == tau0)) tau0 = -INFINITY;
+        }
+        if (lh == 0) s_tau[wave * 32 + li] = tau0;
     }
     // ---- block loader: thread e covers float4 e of the 64 x CP block (register-staged, written to the other buffer after the block's products)
     // in two parts (one per 32-candidate tile of the block in flight), so that only half of a block's float4s are live at a time
@@ -250,17 +306,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     };
-#pragma unroll
-    for (int part = 0; part < NPART; ++part) { gload(0, part); lstore(smem, part); }
-    __syncthreads();
-
     float qxx[16], tau[16];
     float setv[16][2];
     int seti[16][2];
 #pragma unroll
+    for (int part = 0; part < NPART; ++part) { gload(0, part); lstore(smem, part); }
+    __syncthreads();
+#pragma unroll
     for (int r = 0; r < 16; ++r) {
         qxx[r] = s_qxx[wave * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)];
-        tau[r] = -INFINITY;
+        tau[r] = s_tau[wave * 32 + 8 * (r >> 2) + 4 * lh + (r & 3)];
         setv[r][0] = setv[r][1] = -INFINITY;
         seti[r][0] = seti[r][1] = 0;
     }
@@ -310,7 +365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     } while (mask);
                     const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, setv[r][0]), k - 1));
                     const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, setv[r][1]), k - 1));
-                    tau[r] = lh ? t1 : t0;
+                    tau[r] = fmaxf(tau[r], lh ? t1 : t0);        // (never below the warm-start threshold; without one the list's k-th entry only rises anyway)
                 }
             }
             if (more && t < NPART) lstore(nxt, t);
@@ -329,21 +384,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 template <int CP>
-static void launch_knn_mfma(const float* f, int ldf, int C, int32_t* idx, int B, int M, int m_stride_rows, int k, hipStream_t s) {
-    constexpr size_t lds = (2 * (size_t)KM_TC * (CP + 4) + 128) * sizeof(float);
+static void launch_knn_mfma(const float* f, int ldf, int C, int32_t* idx, int B, int M, int m_stride_rows, int k, hipStream_t s, const int32_t* warm) {
+    constexpr size_t lds = (2 * (size_t)KM_TC * (CP + 4) + 256) * sizeof(float);
     static PerDeviceOnce attr_once;
     attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_mfma_kernel<CP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); return 0; });
     char name[80];
     snprintf(name, sizeof name, "void fc::knn_mfma_kernel<%d>(float const*, int, int, int*, int, int, int)", CP);
     ProfScope ps(name, 2.0 * B * (double)M * M * C, 4.0 * B * (double)M * (C + k), s);
-    hipLaunchKernelGGL(knn_mfma_kernel<CP>, dim3((M + 127) / 128, B), dim3(256), lds, s, f, ldf, C, idx, M, m_stride_rows, k);
+    hipLaunchKernelGGL(knn_mfma_kernel<CP>, dim3((M + 127) / 128, B), dim3(256), lds, s, f, ldf, C, idx, M, m_stride_rows, k, warm);
     FC_HIP(hipGetLastError());
 }
 
+int g_knn_warm = 1;          // knob 32: 1 = a level's search starts from the previous level's neighbour sets where the caller hands them over (shipped), 0 = never
 int g_knn_mfma = 1;          // knob 24: 1 = Gram tiles on the matrix cores + sorted register lists where the launch fills the chip (shipped), 2 = always (tests),
                              // 0 = the lane-per-candidate kernel above
 
-void launch_knn(const float* f, int ldf, int C, int32_t* idx, int B, int M, int m_stride_rows, int k, hipStream_t s) {
+// warm: k neighbours per query of the same cloud from another feature space (may alias idx: a workgroup reads its own queries' sets before it
+// writes them), or null; used by the matrix-core kernel only -- the result is the exact top-k set either way
+void launch_knn(const float* f, int ldf, int C, int32_t* idx, int B, int M, int m_stride_rows, int k, hipStream_t s, const int32_t* warm) {
+    if (!g_knn_warm) warm = nullptr;
     if (k > 64 || k < 1) throw Error(FC_ERR_UNSUPPORTED, "knn: k must be in [1, 64]");
     if (M < k) throw Error(FC_ERR_INVALID, "knn: fewer points than neighbours (torch.topk would raise as well)");
     const int Cp = round_up(C, 4);
@@ -356,11 +415,11 @@ void launch_knn(const float* f, int ldf, int C, int32_t* idx, int B, int M, int 
         // workgroups of the kernel below finish a C1 batch in 0.37 ms against 2.7)
         if (Cp8 && ldf >= Cp8 && (g_knn_mfma == 2 || M >= 2048)) {
             switch (Cp8) {
-                case 8: launch_knn_mfma<8>(f, ldf, C, idx, B, M, m_stride_rows, k, s); break;
-                case 16: launch_knn_mfma<16>(f, ldf, C, idx, B, M, m_stride_rows, k, s); break;
-                case 32: launch_knn_mfma<32>(f, ldf, C, idx, B, M, m_stride_rows, k, s); break;
-                case 64: launch_knn_mfma<64>(f, ldf, C, idx, B, M, m_stride_rows, k, s); break;
-                default: launch_knn_mfma<128>(f, ldf, C, idx, B, M, m_stride_rows, k, s); break;
+                case 8: launch_knn_mfma<8>(f, ldf, C, idx, B, M, m_stride_rows, k, s, warm); break;
+                case 16: launch_knn_mfma<16>(f, ldf, C, idx, B, M, m_stride_rows, k, s, warm); break;
+                case 32: launch_knn_mfma<32>(f, ldf, C, idx, B, M, m_stride_rows, k, s, warm); break;
+                case 64: launch_knn_mfma<64>(f, ldf, C, idx, B, M, m_stride_rows, k, s, warm); break;
+                default: launch_knn_mfma<128>(f, ldf, C, idx, B, M, m_stride_rows, k, s, warm); break;
             }
             return;
         }

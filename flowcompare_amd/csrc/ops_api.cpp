@@ -17,7 +17,7 @@ struct TmpBuf {
 }  // namespace fc
 
 
-namespace fc { void one_acc_gemm_debug(const float*, const float*, const float*, float, float*, int, int, int, hipStream_t); long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; extern int g_spline_wide_dma; extern int g_spline_wide_colgroup; extern int g_linear_wide; extern int g_attn_stagger; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
+namespace fc { void one_acc_gemm_debug(const float*, const float*, const float*, float, float*, int, int, int, hipStream_t); long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; extern int g_spline_wide_dma; extern int g_spline_wide_colgroup; extern int g_linear_wide; extern int g_attn_stagger; extern int g_knn_warm; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }
 
 extern "C" {
@@ -49,6 +49,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 24) fc::g_knn_mfma = value;          /* 1 = k-NN Gram tiles on the matrix cores (default), 0 = lane-per-candidate kernel */
     else if (key == 27) fc::g_spline_wide_dma = value;   /* developer builds: DMA pieces per phase of the wide fused spline kernel (spline_wide.hip) */
     else if (key == 29) fc::g_linear_wide = value;       /* hidden layers of the coupling MLP on the 256 x 256 one-accumulator kernel: 0 = off (default: measured no faster than the chain), 1 = for scenes of >= 2048 target points, 2 = at any size */
+    else if (key == 32) fc::g_knn_warm = value;         /* 1 = DGCNN levels 1-3 start their k-NN stream from the previous level's neighbour sets (default; exact either way), 0 = from -inf */
     else if (key == 31) fc::g_train_wide = value;       /* 1 = training Linear layers with >= 1024 outputs (the spline parameter layer) on the 256 x 256 one-accumulator loop (default), 0 = on the fp32-A 128 x 128 loop, 3 = 1 with non-temporal stores of a GB-sized output (measured slower) */
     else if (key == 30) fc::g_attn_stagger = value;     /* 1 = split-fp16 attention as one 512-thread workgroup of two staggered wave groups, 0 = the four-wave kernel (default); bit-identical */
     else if (key == 28) fc::g_spline_wide_colgroup = value;   /* column-group size of its tile order (-1 = shipped) */
@@ -224,6 +225,20 @@ int fc_op_knn_f32(const float* f, int32_t* idx, int32_t B, int32_t M, int32_t C,
     TmpBuf fp((size_t)B * M * cp * 4);
     launch_pack_rows(f, C, C, fp.f(), cp, 0, cp, B * M, s);
     launch_knn(fp.f(), cp, C, idx, B, M, M, k, s);
+    FC_HIP(hipStreamSynchronize(s));
+    FC_API_END
+}
+
+// the same search started from given neighbour sets (what the DGCNN engine does between its levels): idx_warm [B, M, k] int32, may equal idx
+int fc_op_knn_warm_f32(const float* f, const int32_t* idx_warm, int32_t* idx, int32_t B, int32_t M, int32_t C, int32_t k, void* stream) {
+    FC_API_BEGIN
+    using namespace fc;
+    if (!f || !idx || !idx_warm || B < 1 || M < 1 || C < 1) throw Error(FC_ERR_INVALID, "fc_op_knn_warm_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int cp = round_up(C, 32);
+    TmpBuf fp((size_t)B * M * cp * 4);
+    launch_pack_rows(f, C, C, fp.f(), cp, 0, cp, B * M, s);
+    launch_knn(fp.f(), cp, C, idx, B, M, M, k, s, idx_warm);
     FC_HIP(hipStreamSynchronize(s));
     FC_API_END
 }

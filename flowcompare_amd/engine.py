@@ -27,7 +27,7 @@ EXPORTS = [
     "fc_paconv_create", "fc_paconv_destroy", "fc_paconv_out_dim", "fc_paconv_workspace_bytes", "fc_paconv_embed_f32", "fc_op_fps_f32",
     "fc_range_check_defer", "fc_range_check_resolve", "fc_range_check_pending",
     "fc_profile_enable", "fc_profile_reset", "fc_profile_filter", "fc_profile_stride", "fc_profile_report",
-    "fc_op_linear_f32", "fc_op_mlp_hidden_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_rqspline_f32",
+    "fc_op_linear_f32", "fc_op_mlp_hidden_f32", "fc_op_attention_f32", "fc_op_knn_f32", "fc_op_knn_warm_f32", "fc_op_rqspline_f32",
     "fc_stage_fps_f32", "fc_stage_co_unit_sphere_f32", "fc_clamp_infs_f32", "fc_change_map_f32",
     "fc_train_linear_pack_bytes", "fc_train_linear_pack_f32", "fc_train_linear_fwd_f32", "fc_train_linear_act_fwd_f32", "fc_train_linear_dgrad_f32", "fc_train_linear_dgrad_act_f32",
     "fc_train_linear_wgrad_ws_bytes", "fc_train_linear_wgrad_f32", "fc_train_act_fwd_f32", "fc_train_act_bwd_f32",
@@ -483,12 +483,20 @@ def op_attention(q, k, v, scale):
     return out
 
 
-def op_knn(f, k):
+def op_knn(f, k, warm=None):
+    """k nearest neighbours in feature space [B, M, C] -> int32 [B, M, k] (unordered sets); `warm`: neighbour sets [B, M, k] of the same cloud from
+    another feature space to start the search from (the result is the exact top-k either way)."""
     f = _dev_f32(f)
     B, M, C = f.shape
     idx = torch.empty(B, M, k, dtype=torch.int32, device=f.device)
     with torch.cuda.device(f.device):
-        _check(lib().fc_op_knn_f32(_ptr(f), _ptr(idx), B, M, C, k, _stream()))
+        if warm is None:
+            _check(lib().fc_op_knn_f32(_ptr(f), _ptr(idx), B, M, C, k, _stream()))
+        else:
+            warm = warm.to(device=f.device, dtype=torch.int32).contiguous()
+            if tuple(warm.shape) != (B, M, k):
+                raise RuntimeError(f"op_knn: warm sets have shape {tuple(warm.shape)}, expected {(B, M, k)}")
+            _check(lib().fc_op_knn_warm_f32(_ptr(f), _ptr(warm), _ptr(idx), B, M, C, k, _stream()))
     return idx
 
 

@@ -308,6 +308,35 @@ def test_knn_random_vs_fp64(B, M, C, k, knn_kernel):
     assert (idx == torch.arange(M)[None, :, None]).any(-1).all()  # self is always a neighbour
 
 
+@pytest.mark.parametrize("B,M,C", [(2, 2048, 64), (1, 4096, 128), (2, 1500, 6), (1, 16384, 64)])
+def test_knn_warm_start_returns_the_same_sets(B, M, C):
+    """Round 4: the DGCNN levels 1-3 start their k-NN stream from the previous level's neighbour sets (csrc/knn.hip, models/pytorch_gcn.py:43-60:
+    four searches of one cloud in successive feature spaces).  The warm sets only give the initial threshold, so the result must be the
+    SAME SET as the cold search whatever they hold: the true neighbours in a nearby feature space (the real case), random indices (a useless
+    bound), sets with repeated indices or the query in every slot (no bound at all), out-of-range indices."""
+    L = engine.lib()
+    k = 40
+    f = _rand(B, M, C, seed=21)
+    g = torch.Generator().manual_seed(22)
+    near = f + 0.3 * torch.randn(B, M, C, generator=g)
+    try:
+        assert L.fc_debug_set(24, 2) == 0                          # the matrix-core kernel at any size
+        cold = engine.op_knn(f.to(DEV), k).cpu().long().sort(-1)[0]
+        warm_sets = {
+            "neighbours of a perturbed cloud": engine.op_knn(near.to(DEV), k).cpu(),
+            "random indices": torch.randint(0, M, (B, M, k), generator=g, dtype=torch.int32),
+            "the query in every slot": torch.arange(M, dtype=torch.int32)[None, :, None].expand(B, M, k).contiguous(),
+            "one index repeated": torch.randint(0, M, (B, M, 1), generator=g, dtype=torch.int32).expand(B, M, k).contiguous(),
+            "out of range": torch.full((B, M, k), M + 5, dtype=torch.int32),
+            "its own result": cold.int(),
+        }
+        for name, w in warm_sets.items():
+            got = engine.op_knn(f.to(DEV), k, warm=w.to(DEV)).cpu().long().sort(-1)[0]
+            assert torch.equal(got, cold), f"warm start from {name}: {(got != cold).any(-1).sum().item()} of {B * M} sets differ"
+    finally:
+        L.fc_debug_set(24, 1)
+
+
 def test_spline_golden_forward_and_inverse():
     z = np.load(os.path.join(GOLDEN, "op_spline.npz"))
     x, w, h, d = (torch.from_numpy(z[k]).float() for k in ("x", "w", "h", "d"))
