@@ -388,8 +388,8 @@ static void launch_knn_mfma(const float* f, int ldf, int C, int32_t* idx, int B,
     constexpr size_t lds = (2 * (size_t)KM_TC * (CP + 4) + 256) * sizeof(float);
     static PerDeviceOnce attr_once;
     attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_mfma_kernel<CP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); return 0; });
-    char name[80];
-    snprintf(name, sizeof name, "void fc::knn_mfma_kernel<%d>(float const*, int, int, int*, int, int, int)", CP);
+    char name[112];
+    snprintf(name, sizeof name, "void fc::knn_mfma_kernel<%d>(float const*, int, int, int*, int, int, int, int const*)", CP);
     ProfScope ps(name, 2.0 * B * (double)M * M * C, 4.0 * B * (double)M * (C + k), s);
     hipLaunchKernelGGL(knn_mfma_kernel<CP>, dim3((M + 127) / 128, B), dim3(256), lds, s, f, ldf, C, idx, M, m_stride_rows, k, warm);
     FC_HIP(hipGetLastError());

@@ -47,7 +47,7 @@ def test_kernel_peaks_by_symbol():
     assert (n, peak) == (3, 2500.0)
     n, peak, _ = bench.kernel_peak("void fc::gemm_f32_kernel<128, 128, 4, 2, 0, 3>(fc::GemmParams)")
     assert (n, peak) == (6, 2500.0)
-    n, peak, _ = bench.kernel_peak("void fc::knn_mfma_kernel<64>(float const*, int, int, int*, int, int, int)")
+    n, peak, _ = bench.kernel_peak("void fc::knn_mfma_kernel<64>(float const*, int, int, int*, int, int, int, int const*)")
     assert (n, peak) == (1, 157.3)
     r = bench.roofline_of({"kernel": "void fc::attn16_kernel<64>(fc::Attn16Params)", "launches": 2, "ms": 1.0, "flops": 2.0e9, "bytes": 0.0}, {}, {}, "no pass")
     assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / 2500.0) < 1e-12 and abs(r["frac_issued"] - 3 * r["frac"]) < 1e-12 and r["traffic"] is None and r["traffic_note"] == "no pass"
