@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FCFLOW_LIB", os.path.join(_HERE, "libfcflow.so"))   # FCFLOW_LIB: A/B another build in profiles/kernel_bench.py
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 FLOW_TYPES = {"AffineCoupling": 0, "RationalQuadraticSplineCoupling": 1, "ExponentialCoupling": 2}
 SCALE_FNS = {"exp": 0, "sigmoid": 1}

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 6
+#define FC_ABI_VERSION 7
 
 enum fc_status {
     FC_OK = 0,
@@ -230,7 +230,7 @@ int fc_op_attention_f32(const float* q, const float* k, const float* v, float* o
 int fc_op_knn_f32(const float* f, int32_t* idx, int32_t B, int32_t M, int32_t C, int32_t k, void* stream);
 /* The same search started from given neighbour sets idx_warm [B,M,k] (may equal idx): what the DGCNN embedder does between its four
  * levels, which search one cloud in successive feature spaces (models/pytorch_gcn.py:43-60).  Any k distinct candidates bound the k-th
- * best from below, so the stream skips everything under that bound; the returned set is the exact top-k whatever idx_warm holds. */
+ * best from below, so the stream skips everything under that bound; the returned set is the exact top-k whatever idx_warm holds.  ABI v7. */
 int fc_op_knn_warm_f32(const float* f, const int32_t* idx_warm, int32_t* idx, int32_t B, int32_t M, int32_t C, int32_t k, void* stream);
 
 /* Elementwise rational-quadratic spline with linear tails (models/spline_coupling.py:24-169).
