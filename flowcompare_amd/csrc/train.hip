@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 
 #include "activations.h"
@@ -537,10 +538,15 @@ static PackedLinear packed_transposed(const TrainLinearLayout& L, const void* pa
 // limb split (spline_wide.hip EPI 3).  One entry per device; taking it consumes it (a panel that reached the GEMM by another route finds none
 // and runs on the fp32-A loop).
 namespace {
-struct RowMaxSlot { float* buf = nullptr; int cap = 0; const float* tensor = nullptr; int rows = 0; hipStream_t s = nullptr; };
+struct RowMaxSlot { float* buf = nullptr; int cap = 0; const float* tensor = nullptr; int rows = 0; hipStream_t s = nullptr; unsigned long long stamp = 0; };
 std::mutex g_rowmax_mu;
 RowMaxSlot g_rowmax[16];
+// an entry is good for the next few training-Linear calls only (the parameter layer's weight and data gradient follow its spline backward
+// directly): a panel that is merely allocated where an earlier gradient panel lived never meets that panel's row maxima
+std::atomic<unsigned long long> g_train_calls{0};
+constexpr unsigned long long kRowMaxLifetime = 4;
 }
+void train_call_tick() { g_train_calls.fetch_add(1); }
 float* train_rowmax_reserve(const float* tensor, int rows, hipStream_t s) {
     int dev = 0;
     FC_HIP(hipGetDevice(&dev));
@@ -552,7 +558,7 @@ float* train_rowmax_reserve(const float* tensor, int rows, hipStream_t s) {
         FC_HIP(hipMalloc((void**)&r.buf, (size_t)rows * 4));
         r.cap = rows;
     }
-    r.tensor = tensor; r.rows = rows; r.s = s;
+    r.tensor = tensor; r.rows = rows; r.s = s; r.stamp = g_train_calls.fetch_add(1) + 1;
     return r.buf;
 }
 const float* train_rowmax_take(const float* tensor, int rows, hipStream_t s) {
@@ -561,7 +567,8 @@ const float* train_rowmax_take(const float* tensor, int rows, hipStream_t s) {
     if (dev < 0 || dev >= 16) return nullptr;
     std::lock_guard<std::mutex> lk(g_rowmax_mu);
     RowMaxSlot& r = g_rowmax[dev];
-    if (!r.buf || r.tensor != tensor || r.rows < rows || r.s != s) return nullptr;
+    const unsigned long long now = g_train_calls.load();
+    if (!r.buf || r.tensor != tensor || r.rows < rows || r.s != s || now - r.stamp > kRowMaxLifetime) return nullptr;
     r.tensor = nullptr;
     return r.buf;
 }
@@ -603,6 +610,7 @@ int fc_train_linear_pack_f32(const float* W, const float* bias, int32_t N, const
 int fc_train_linear_fwd_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* const* x, const int32_t* ldx,
                             int32_t rows_pad, const float* residual, int32_t ldr, float* u, int32_t ldu, int32_t* ovf, void* stream) {
     FC_API_BEGIN
+    train_call_tick();
     const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
     if (!pack || !x || !ldx || rows_pad < 1 || rows_pad % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "fc_train_linear_fwd_f32: bad argument (rows_pad must be a multiple of 256)");
     ASeg a[3] = {};
@@ -631,6 +639,7 @@ int fc_train_linear_act_fwd_f32(const void* pack, int32_t N, const int32_t* seg_
                                 int32_t rows_pad, const float* residual, int32_t ldr, float* u, float* y, int32_t ldu, int32_t act, int32_t* ovf,
                                 void* stream) {
     FC_API_BEGIN
+    train_call_tick();
     const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
     if (!pack || !x || !ldx || rows_pad < 1 || rows_pad % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "fc_train_linear_act_fwd_f32: bad argument (rows_pad must be a multiple of 256)");
     if (act != FC_ACT_GELU && act != FC_ACT_RELU && act != FC_ACT_ELU) throw Error(FC_ERR_INVALID, "fc_train_linear_act_fwd_f32: act must be GELU, RELU or ELU");
@@ -650,6 +659,7 @@ int fc_train_linear_act_fwd_f32(const void* pack, int32_t N, const int32_t* seg_
 int fc_train_linear_dgrad_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu, int32_t rows_pad,
                               float* dx, int32_t lddx, int32_t* ovf, void* stream) {
     FC_API_BEGIN
+    train_call_tick();
     const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
     if (!pack || rows_pad < 1 || rows_pad % ROW_PAD != 0) throw Error(FC_ERR_INVALID, "fc_train_linear_dgrad_f32: bad argument (rows_pad must be a multiple of 256)");
     check_panel(du, ldu, L.N_pad, "du");
@@ -680,6 +690,7 @@ int fc_train_linear_dgrad_f32(const void* pack, int32_t N, const int32_t* seg_wi
 int fc_train_linear_dgrad_act_f32(const void* pack, int32_t N, const int32_t* seg_widths, int32_t nseg, const float* du, int32_t ldu, int32_t rows_pad,
                                   float* dx, int32_t lddx, const float* addend, const float* u_prev, int32_t act, int32_t* ovf, void* stream) {
     FC_API_BEGIN
+    train_call_tick();
     const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
     if (!pack || rows_pad < 1 || rows_pad % ROW_PAD != 0 || nseg != 1) throw Error(FC_ERR_INVALID, "fc_train_linear_dgrad_act_f32: bad argument (one input segment, rows_pad a multiple of 256)");
     if (act != FC_ACT_GELU && act != FC_ACT_RELU && act != FC_ACT_ELU) throw Error(FC_ERR_INVALID, "fc_train_linear_dgrad_act_f32: act must be GELU, RELU or ELU");
@@ -714,6 +725,7 @@ int fc_train_linear_wgrad_f32(int32_t N, const int32_t* seg_widths, int32_t nseg
                               const int32_t* ldx, int32_t rows, float* dW, float* db, int32_t accumulate, void* ws, size_t ws_bytes, int32_t* ovf,
                               void* stream) {
     FC_API_BEGIN
+    train_call_tick();
     const TrainLinearLayout L = train_layout(N, seg_widths, nseg);
     if (!x || !ldx || rows < 1 || (!dW && !db)) throw Error(FC_ERR_INVALID, "fc_train_linear_wgrad_f32: bad argument");
     check_panel(du, ldu, L.N_pad, "du");

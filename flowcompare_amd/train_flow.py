@@ -51,6 +51,18 @@ def _kv(pre, ctx_panel, E, ctx_rows):
     return (T.linear_act([ctx_panel], [E], w[:inner], None, ctx_rows), T.linear_act([ctx_panel], [E], w[inner:], None, ctx_rows))
 
 
+_TRI_INDEX_CACHE = {}
+
+
+def _tri_indices(D, dev):
+    """Strict lower / upper triangle index pairs of a D x D matrix on `dev` (115 LinearLU layers ask for the same two tensors every step)."""
+    key = (D, str(dev))
+    hit = _TRI_INDEX_CACHE.get(key)
+    if hit is None:
+        hit = _TRI_INDEX_CACHE[key] = (torch.tril_indices(D, D, -1, device=dev), torch.triu_indices(D, D, 1, device=dev))
+    return hit
+
+
 def _perm_weight(perm, cfg):
     """The permuter between layers as a matrix W (z = W x) and its log|det|, built in parameter space (torch autograd carries dW back):
     LinearLU (models/permuters.py:148-169: W = L U, unit-lower L, diag(U) = softplus(u) + eps), Permuter / random_permute (:55-70: a
@@ -61,8 +73,7 @@ def _perm_weight(perm, cfg):
         D = perm.num_features
         dev = perm.lower_entries.device
         diag = torch.nn.functional.softplus(perm.unconstrained_upper_diag) + perm.eps
-        il = torch.tril_indices(D, D, -1, device=dev)
-        iu = torch.triu_indices(D, D, 1, device=dev)
+        il, iu = _tri_indices(D, dev)
         L = torch.eye(D, device=dev, dtype=diag.dtype).index_put((il[0], il[1]), perm.lower_entries)
         U = torch.diag(diag).index_put((iu[0], iu[1]), perm.upper_entries)
         # L U on the library's own training Linear (y = x W^T with x = L, W = U^T): no vendor BLAS on the training path
