@@ -25,6 +25,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 EXTRA_FLAGS = {"premlp.hip": ["-fno-slp-vectorize"], "attention.hip": ["-fno-slp-vectorize"],
                # mlprows.hip: the epilogue is hand-placed in micro-steps behind single MFMAs; SLP packing merges steps of different slots
                "mlprows.hip": ["-fno-slp-vectorize"]}
+# (spline_wide.hip: measured both ways on one box, profiles/r04D_*: 68.1 against 68.5 ms per C2 step, training step 1052 against 1050 ms -- no flag)
 for _kv in os.environ.get("FC_EXTRA_FLAGS", "").split(";"):
     if ":" in _kv:
         EXTRA_FLAGS.setdefault(_kv.split(":", 1)[0], []).extend(_kv.split(":", 1)[1].split(","))
