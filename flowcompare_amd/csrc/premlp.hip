@@ -374,6 +374,18 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     PR_STAMP(1)
 
     int buf = 0;                                             // stage that holds (is receiving) the chunk about to be multiplied
+    // diagnostic build (-DFC_PREMLP_WAIT_STAMPS, profiles/micro/premlp_rows_stamps.py): cycles this wave waited for its DMA pieces / at the chunk
+    // barriers.  Not in the shipped build: the two counters cost the kernel its last registers (248 bytes of scratch per lane).
+#ifdef FC_PREMLP_WAIT_STAMPS
+    unsigned long long t_vm = 0, t_bar = 0, tw0 = 0, tw1 = 0;
+#define PR_WAIT_T0 tw0 = __builtin_amdgcn_s_memtime();
+#define PR_WAIT_T1 tw1 = __builtin_amdgcn_s_memtime();
+#define PR_WAIT_T2 { const unsigned long long tw2 = __builtin_amdgcn_s_memtime(); t_vm += tw1 - tw0; t_bar += tw2 - tw1; }
+#else
+#define PR_WAIT_T0
+#define PR_WAIT_T1
+#define PR_WAIT_T2
+#endif
 
     // MFMAs of one chunk: (am, ac) = W[32 c .. 32 c + 31][:] . act  (main / cross-product accumulators of the two 16-feature blocks)
     auto chunk_mma = [&](const PreMlpLayer& L, const PreMlpLayer* nextL, int nextc, auto fullk_tag, floatx4 (&am)[2], floatx4 (&ac)[2], auto&& after_dma) __attribute__((always_inline)) {
@@ -382,8 +394,11 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { am[mb][i] = 0.f; ac[mb][i] = 0.f; }
+        PR_WAIT_T0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // own pieces of this chunk have landed
+        PR_WAIT_T1
         __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
+        PR_WAIT_T2
         if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
         grp ^= 1;
         after_dma();                                                    // (loads that must not sit in front of the wait above: they get this chunk's time to land)
@@ -496,8 +511,11 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { am[mb][i] = 0.f; ac[mb][i] = 0.f; }
+            PR_WAIT_T0
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // own pieces of this chunk have landed
+            PR_WAIT_T1
             __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
+            PR_WAIT_T2
             if (c + 1 < NLU) pr_dma(p.lu, c + 1, smc + (buf ^ 1) * PRB, wave, lane, grp);
             else pr_dma(p.in, 0, smc + (buf ^ 1) * PRB, wave, lane, grp);
             grp ^= 1;
@@ -621,6 +639,15 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     if (amax >= 65504.0f) atomicOr(p.ovf, 1);
     PR_STAMP(7)
     if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + 15] = wall_clock64();
+#ifdef FC_PREMLP_WAIT_STAMPS
+    if (p.stamps && (threadIdx.x == 0 || threadIdx.x == 256)) {      // (wave 0: issues the even chunks' pieces; wave 4: the odd ones')
+        p.stamps[(size_t)blockIdx.x * 16 + 8 + 2 * (threadIdx.x >> 8)] = t_vm;
+        p.stamps[(size_t)blockIdx.x * 16 + 9 + 2 * (threadIdx.x >> 8)] = t_bar;
+    }
+#endif
+#undef PR_WAIT_T0
+#undef PR_WAIT_T1
+#undef PR_WAIT_T2
 #undef PR_STAMP
 }
 

@@ -30,3 +30,6 @@ ghz = np.median((st[:, 7] - st[:, 0]) / wall) / 1e3
 print(f"{len(st)} workgroups, span {(st[:, 15].max() - st[:, 14].min()) / 100.0:.1f} us, workgroup life {wall.mean():.1f} us, clock {ghz:.2f} GHz")
 for k, nm in enumerate(["input split + biases", "in_layer (8 chunks, K 160)", "hidden 0", "hidden 1 (+ residual)", "out_layer", "LayerNorm", "q projection (2 chunks)"]):
     print(f"    {nm:28s} mean {d[:, k].mean():8.0f} cyc ({d[:, k].mean() / ghz / 1e3:6.2f} us)  p10 {np.percentile(d[:, k], 10):8.0f} p90 {np.percentile(d[:, k], 90):8.0f}")
+tot = (st[:, 7] - st[:, 0]).mean()
+for w, nm in ((0, "wave 0"), (1, "wave 4")):
+    print(f"    {nm}: waited for its DMA pieces {st[:, 8 + 2 * w].mean():8.0f} cyc ({100 * st[:, 8 + 2 * w].mean() / tot:4.1f} %), at the chunk barriers {st[:, 9 + 2 * w].mean():8.0f} cyc ({100 * st[:, 9 + 2 * w].mean() / tot:4.1f} %) of {tot:.0f}")
