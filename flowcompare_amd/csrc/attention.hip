@@ -457,6 +457,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 // so two of the three slots pair one wave's MFMAs with its partner's VALU work -- the explicit alternation that took the round-4 spline GEMM
 // from 69 % to 86 % matrix-pipe busy (profiles/micro/wide_gemm_probe.hip).  Same MFMAs in the same order on the same operands, same softmax
 // arithmetic: results are BIT-IDENTICAL to attn16_kernel (tests/test_gpu_ops.py::test_attention_staggered_groups_equal_the_four_wave_kernel).
+// MEASURED: no gain (26.6 against 26.2 ms per C2 step; slot stamps, knob 20 = 5: S 2316 | PV 1844, softmax 2324 | S 1476, PV 1356 | softmax
+// 2696 cycles per tile) -- the softmax slot is VALU issue time that two waves per SIMD need 2 x 2300 cycles of against 2 x 1536 of MFMA, so the
+// kernel is VALU-bound under any interleaving.  Kept behind knob 30 with its equality test; attn16_kernel is what ships.
 // K / V tiles: both groups read the same two LDS stages; tile t + 1 is requested in slot 1 of tile t and stored in slot 3, after the last
 // reader of the stage it replaces (group 1's P V (t - 1) in slot 1) and a barrier before its first reader (group 0's S(t + 1)).
 template <int DH>
