@@ -43,6 +43,15 @@ __device__ __forceinline__ void limb_split2(float x0, float x1, unsigned& hi, un
     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(lo) : "v"(d0), "s"(2048.0f));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(lo) : "v"(d1), "s"(2048.0f));
 }
+// One-accumulator form (common.h): hi = rn16(x), lo = rn16(x - hi) UNSCALED (the caller has scaled x so that lo stays a normal number where
+// it matters).  Four VALU instructions for the pair.
+__device__ __forceinline__ void limb_split2u(float x0, float x1, unsigned& hi, unsigned& lo) {
+    float d0, d1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hi), "v"(x1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
+}
 // The same with run-time (wave-uniform) scales: hi = rn16(x s1), lo = rn16((x s1 - hi) s2).  (1, 2048) gives limb_split2's bits exactly (the
 // products by 1 are exact); (kOneAccActScale, 1) the one-accumulator form of spline_wide.hip (common.h).  Six VALU instructions for the pair.
 __device__ __forceinline__ void limb_split2s(float x0, float x1, float s1, float s2, unsigned& hi, unsigned& lo) {
@@ -73,6 +82,16 @@ __device__ __forceinline__ void limb_split8(const float (&x)[8], fc_f16x8& hi, f
     limb_split2(x[2], x[3], a, b); h[1] = a; l[1] = b;
     limb_split2(x[4], x[5], a, b); h[2] = a; l[2] = b;
     limb_split2(x[6], x[7], a, b); h[3] = a; l[3] = b;
+    hi = __builtin_bit_cast(fc_f16x8, h);
+    lo = __builtin_bit_cast(fc_f16x8, l);
+}
+__device__ __forceinline__ void limb_split8_unscaled(const float (&x)[8], fc_f16x8& hi, fc_f16x8& lo) {
+    fc_u32x4 h, l;
+    unsigned a, b;
+    limb_split2u(x[0], x[1], a, b); h[0] = a; l[0] = b;
+    limb_split2u(x[2], x[3], a, b); h[1] = a; l[1] = b;
+    limb_split2u(x[4], x[5], a, b); h[2] = a; l[2] = b;
+    limb_split2u(x[6], x[7], a, b); h[3] = a; l[3] = b;
     hi = __builtin_bit_cast(fc_f16x8, h);
     lo = __builtin_bit_cast(fc_f16x8, l);
 }

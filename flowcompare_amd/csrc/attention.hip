@@ -184,10 +184,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 
 // =====================================================================================================================
 // Split-fp16 attention (the default when the caller is inside an Fp16Guard scope, DH <= 64).
-// Same flash structure, but every product runs on the 16-bit matrix cores with fp32-equivalent operands (gemm.hip, VAR 5):
-// x = hi + lo'/2048 in two fp16 limbs, a*b ~= ah*bh + (ah*bl' + al'*bh)/2048 with the h*h products and the cross products in
-// separate fp32 accumulators.  12 MFMAs (32 cycles) per 32x32 score block instead of 32 fp32-input MFMAs (64 cycles).
-//   * K and V of the layer are split ONCE by kv_limbs_kernel into row images [key][hi DH | lo' DH] (the fp32 kernel above
+// Same flash structure, but every product runs on the 16-bit matrix cores with fp32-equivalent operands in the ONE-ACCUMULATOR limb
+// form of spline_wide.hip (round 4; rounds 2-3 kept x = hi + lo'/2048 with separate main / cross-product accumulators): q, k, v are
+// x * 16 = hi + lo with lo = rn16(x 16 - hi) unscaled, the probabilities p * 2^14 = hi + lo, a*b ~= ah*bh + ah*bl + al*bh in one fp32
+// accumulator.  12 MFMAs (32 cycles) per 32x32 score block instead of 32 fp32-input MFMAs (64 cycles); against the two-accumulator
+// form: no fold per score, 4 instead of 5 VALU per pair of probabilities in the limb split, 64 fewer accumulator registers.
+//   * K and V of the layer are split ONCE by kv_limbs_kernel into row images [key][hi DH | lo DH] (the fp32 kernel above
 //     re-reads them per 128-query workgroup; here 32 workgroups per scene would redo the same conversion);
 //   * S^T = K Q^T: A = K rows (ds_read_b128 per limb), B = Q limbs held in registers for the whole kernel;
 //   * P: the S^T accumulator has the query on the lane and 32 keys in its registers, so registers 8s..8s+7 split into limbs
@@ -213,10 +215,10 @@ struct Attn16Params {
     int kv_pitch;                   // row pitch of the k16 / v16 images in 16-byte chunks (DH / 4 for the packed images)
     int c16;                        // 1: rows are slices of a GEMM's limb-image output ([16 columns: hi 16 | lo' 16] tiles, GemmEpi::C16)
     float* lse = nullptr;           // optional [B * n_stride]: natural-log sum-exp of every query's scaled scores (training: the backward reuses it)
-    unsigned long long* stamps = nullptr;   // diagnostic knob 20 = 5 (attn16x2_kernel): s_memtime at the slot boundaries of workgroup (0, 0), both groups
 };
 
-// fp32 K / V columns of the projected context -> limb row images; raises *ovf on |x| >= 65504.
+// fp32 K / V columns of the projected context -> limb row images in the ONE-ACCUMULATOR form (common.h kOneAccActScale): x s = hi + lo with
+// lo = rn16(x s - hi) unscaled; raises *ovf when |x s| leaves fp16's range.
 __global__ __launch_bounds__(256) void kv_limbs_kernel(const float* k, int ldk, const float* v, int ldv, unsigned short* k16, unsigned short* v16,
                                                        long rows, int DH, int* ovf) {
     const int c4 = DH / 4;
@@ -232,14 +234,14 @@ __global__ __launch_bounds__(256) void kv_limbs_kernel(const float* k, int ldk, 
             uint2 h, l;
 #pragma unroll
             for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(xs[e]));
-            limb_split2(xs[0], xs[1], h.x, l.x);
-            limb_split2(xs[2], xs[3], h.y, l.y);
+            limb_split2s(xs[0], xs[1], kOneAccActScale, 1.0f, h.x, l.x);
+            limb_split2s(xs[2], xs[3], kOneAccActScale, 1.0f, h.y, l.y);
             unsigned short* dst = (which ? v16 : k16) + row * 2 * DH + c;
             *reinterpret_cast<uint2*>(dst) = h;
             *reinterpret_cast<uint2*>(dst + DH) = l;
         }
     }
-    if (amax >= 65504.0f) atomicOr(ovf, 1);
+    if (!(amax * kOneAccActScale < 65504.0f)) atomicOr(ovf, 1);
 }
 
 template <int DH>
@@ -279,21 +281,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float bq = p.q_bias ? p.q_bias[16 * s + 8 * lh + e] : 0.f;
-                const float x = (xs[e] * rstd + bq) * p.qscale;
+                const float x = (xs[e] * rstd + bq) * (p.qscale * kOneAccActScale);
                 amax = fmaxf(amax, fabsf(x));
                 qh[s][e] = (_Float16)x;
-                ql[s][e] = (_Float16)((x - (float)qh[s][e]) * 2048.0f);
+                ql[s][e] = (_Float16)(x - (float)qh[s][e]);
             }
         }
     }
-    if (amax >= 65504.0f) atomicOr(p.ovf, 1);
+    if (!(amax < 65504.0f)) atomicOr(p.ovf, 1);
 
-    floatx16 om[DT], oc[DT];                                   // main (h*h) and cross-product accumulators of O
+    // ONE accumulator per output (round 4, the limb form of spline_wide.hip): q, k, v are held as hi + lo of x * 16 with lo UNSCALED and the
+    // probabilities as hi + lo of p * 2^14, so that the three limb products hi.hi + hi.lo + lo.hi land at one scale in one fp32 accumulator:
+    // no cross-product accumulator sets (64 registers) and no fold of S per score.  The scales cancel exactly: scores are read as
+    // S / 256 inside the exponent's fma, 2^14 rides in the exponent's offset (row sums carry it too), the output divides by 16 l.
+    floatx16 om[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { om[d][r] = 0.f; oc[d][r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+        for (int r = 0; r < 16; ++r) om[d][r] = 0.f;
+    constexpr float S_INV = 1.0f / (kOneAccActScale * kOneAccActScale), P_EXP = 14.0f;
+    float m_run = -INFINITY, l_run = 0.f;                      // m_run: running maximum of the TRUE scores (log2 domain); l_run: sum of p 2^14
 
     // ---- staging: plain 16-byte copies of the limb images (whole-vector register values: arrays went through scratch)
     typedef unsigned int u32xs __attribute__((ext_vector_type(4 * NCH)));
@@ -338,23 +345,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         const char* sV = sK + VOFF;
 
         // ---- S^T = K Q^T for the two 32-key halves of the tile
-        floatx16 s[2];
+        floatx16 s[2];                                          // 256 x the scores
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
-            floatx16 sm, sc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) s[h2][r] = 0.f;
             const char* kr = sK + (32 * h2 + li) * KP + 16 * lh;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const f16x8 kh = *reinterpret_cast<const f16x8*>(kr + 32 * ks);
                 const f16x8 kl = *reinterpret_cast<const f16x8*>(kr + 2 * DH + 32 * ks);
-                sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sm, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
+                s[h2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[h2], 0, 0, 0);
+                s[h2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[h2], 0, 0, 0);
+                s[h2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[h2], 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[h2][r] = fmaf(sc[r], 1.0f / 2048.0f, sm[r]);
         }
         // ---- mask the tail keys of the last tile
         if (t * 64 + 64 > p.M) {
@@ -373,14 +377,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[h2][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
+        const float m_new = fmaxf(m_run, mt * S_INV);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // 0 on the first tile (m_run = -inf)
+        const float off = P_EXP - m_new;                                     // p 2^14 = exp2(S / 256 - m + 14)
         float lt = 0.f;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[h2][r] - m_new);   // raw v_exp_f32: arguments are <= 0, results below 2^-126 may flush to 0
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[h2][r], S_INV, off));   // raw v_exp_f32: arguments are <= 14, tiny results may flush to 0
                 s[h2][r] = pv;
                 lt += pv;
             }
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
             for (int r = 0; r < 16; ++r) {
                 const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
 #pragma unroll
-                for (int d = 0; d < DT; ++d) { om[d][r] *= ar; oc[d][r] *= ar; }
+                for (int d = 0; d < DT; ++d) om[d][r] *= ar;
             }
         }
         // ---- O += P V, 16 keys per MFMA k-step: A = limbs of P registers 8 s2 .. 8 s2 + 7, B = V via transposed reads
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 {
                     const float x8[8] = {s[h2][8 * s2], s[h2][8 * s2 + 1], s[h2][8 * s2 + 2], s[h2][8 * s2 + 3],
                                          s[h2][8 * s2 + 4], s[h2][8 * s2 + 5], s[h2][8 * s2 + 6], s[h2][8 * s2 + 7]};
-                    limb_split8(x8, ph, pl);                     // (5 VALU per pair of probabilities: this kernel is VALU-bound on exactly this)
+                    limb_split8_unscaled(x8, ph, pl);             // (4 VALU per pair of probabilities: this kernel is VALU-bound on exactly this)
                 }
                 const char* vr = sV + (32 * h2 + 16 * s2) * VP + tr_off;
 #pragma unroll
@@ -418,8 +423,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                                                                                       0, 1, 2, 3, 4, 5, 6, 7));
 #undef FC_TR
                     om[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, om[d], 0, 0, 0);
-                    oc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, oc[d], 0, 0, 0);
-                    oc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, oc[d], 0, 0, 0);
+                    om[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, om[d], 0, 0, 0);
+                    om[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, om[d], 0, 0, 0);
                 }
             }
         }
@@ -429,8 +434,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #undef FC_GLOAD
 #undef FC_LSTORE
 
-    if (p.lse && lane < 32 && q0 + lane < p.N)                   // scores are in the log2 domain (qscale carries log2 e)
-        p.lse[(size_t)b * p.n_stride + q0 + lane] = (m_run + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f;
+    if (p.lse && lane < 32 && q0 + lane < p.N)                   // scores are in the log2 domain (qscale carries log2 e); l_run carries 2^14
+        p.lse[(size_t)b * p.n_stride + q0 + lane] = (m_run - P_EXP + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f;
     // ---- normalise and store: O rows are queries (r&3)+8(r>>2)+4h of this wave, columns d = 32*dt + lane&31
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -440,266 +445,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         if (qi < p.N) {
             float* op = p.out + ((size_t)b * p.n_stride + qi) * p.ldo + li;
 #pragma unroll
-            for (int d = 0; d < DT; ++d) op[32 * d] = (om[d][r] + oc[d][r] * (1.0f / 2048.0f)) / lr;
+            for (int d = 0; d < DT; ++d) op[32 * d] = om[d][r] / (lr * kOneAccActScale);      // (v carries 16, p and l carry 2^14)
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Round 4: the same attention as ONE 512-thread workgroup of two wave GROUPS that alternate matrix and vector work.
-// attn16_kernel's waves run S = K Q^T (24 MFMAs), the softmax (~300 VALU instructions incl. 32 v_exp and the limb split of P) and O += P V
-// (24 MFMAs) in series, and the two co-resident 4-wave workgroups of a CU fall into step: matrix pipes 36-43 % busy while the VALU work of
-// a tile (~1300 cycles per wave) is almost as long as its MFMA work (1536).  Here waves w and w + 4 share a SIMD and belong to different
-// groups; a tile is three SLOTS separated by workgroup barriers:
-//     slot 1:  group 0  S(t)        | group 1  O += P V (t - 1)        (matrix | matrix)
-//     slot 2:  group 0  softmax(t)  | group 1  S(t)                    (vector | matrix)
-//     slot 3:  group 0  O += P V(t) | group 1  softmax(t)              (matrix | vector)
-// so two of the three slots pair one wave's MFMAs with its partner's VALU work -- the explicit alternation that took the round-4 spline GEMM
-// from 69 % to 86 % matrix-pipe busy (profiles/micro/wide_gemm_probe.hip).  Same MFMAs in the same order on the same operands, same softmax
-// arithmetic: results are BIT-IDENTICAL to attn16_kernel (tests/test_gpu_ops.py::test_attention_staggered_groups_equal_the_four_wave_kernel).
-// MEASURED: no gain (26.6 against 26.2 ms per C2 step; slot stamps, knob 20 = 5: S 2316 | PV 1844, softmax 2324 | S 1476, PV 1356 | softmax
-// 2696 cycles per tile) -- the softmax slot is VALU issue time that two waves per SIMD need 2 x 2300 cycles of against 2 x 1536 of MFMA, so the
-// kernel is VALU-bound under any interleaving.  Kept behind knob 30 with its equality test; attn16_kernel is what ships.
-// K / V tiles: both groups read the same two LDS stages; tile t + 1 is requested in slot 1 of tile t and stored in slot 3, after the last
-// reader of the stage it replaces (group 1's P V (t - 1) in slot 1) and a barrier before its first reader (group 0's S(t + 1)).
-template <int DH>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void attn16x2_kernel(const Attn16Params p) {
-    constexpr int KS = DH / 16, DT = DH / 32;
-    constexpr int KP = 4 * DH + 16, VP = 4 * DH + 64;          // LDS row pitches in bytes
-    constexpr int VOFF = 64 * KP;
-    constexpr int STAGE = 64 * (KP + VP);
-    constexpr int CPR = DH / 4;                                // 16-byte chunks per image row
-    constexpr int NCH = 64 * CPR / 512;                        // chunks per thread, tile and image
-    static_assert(NCH >= 1, "head dims of at least 32");
-    extern __shared__ float smem[];
-    char* smc = reinterpret_cast<char*>(smem);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2;
-    const int li = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.y;
-    const int q0 = blockIdx.x * 256 + wave * 32;
-
-    f16x8 qh[KS], ql[KS];
-    float amax = 0.f;
-    {
-        int qi = q0 + li;
-        qi = qi < p.N ? qi : p.N - 1;
-        const size_t qrow = (size_t)b * p.n_stride + qi;
-        const float* qp = p.q + qrow * p.ldq + 8 * lh;
-        float rstd = 1.0f;
-        if (p.q_sumsq) {
-            float ss = 0.f;
-            for (int sb = 0; sb < p.q_slots; ++sb) ss += p.q_sumsq[(size_t)sb * p.q_pitch + qrow];
-            rstd = 1.0f / sqrtf(ss * p.q_inv_width + 1e-5f);
-        }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * s), t1 = *reinterpret_cast<const float4*>(qp + 16 * s + 4);
-            const float xs[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float bq = p.q_bias ? p.q_bias[16 * s + 8 * lh + e] : 0.f;
-                const float x = (xs[e] * rstd + bq) * p.qscale;
-                amax = fmaxf(amax, fabsf(x));
-                qh[s][e] = (_Float16)x;
-                ql[s][e] = (_Float16)((x - (float)qh[s][e]) * 2048.0f);
-            }
-        }
-    }
-    if (amax >= 65504.0f) atomicOr(p.ovf, 1);
-
-    floatx16 om[DT], oc[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { om[d][r] = 0.f; oc[d][r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-
-    typedef unsigned int u32xs __attribute__((ext_vector_type(4 * NCH)));
-    u32xs rk, rv;
-    const uint4* kb = reinterpret_cast<const uint4*>(p.k16) + (size_t)b * p.m_stride * p.kv_pitch;
-    const uint4* vb = reinterpret_cast<const uint4*>(p.v16) + (size_t)b * p.m_stride * p.kv_pitch;
-#define FC_GLOAD2(T_)                                                                         \
-    _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                         \
-        const int c_ = tid + 512 * i, kr_ = c_ / CPR, part_ = c_ - kr_ * CPR;                 \
-        int key_ = (T_) * 64 + kr_;                                                           \
-        key_ = key_ < p.M ? key_ : p.M - 1;                                                   \
-        const int w_ = part_ % (CPR / 2), lb_ = part_ / (CPR / 2);                             \
-        const int sp_ = p.c16 ? (w_ >> 1) * 4 + lb_ * 2 + (w_ & 1) : part_;                    \
-        const uint4 a_ = kb[(size_t)key_ * p.kv_pitch + sp_], b_ = vb[(size_t)key_ * p.kv_pitch + sp_];  \
-        rk[4 * i] = a_.x; rk[4 * i + 1] = a_.y; rk[4 * i + 2] = a_.z; rk[4 * i + 3] = a_.w;     \
-        rv[4 * i] = b_.x; rv[4 * i + 1] = b_.y; rv[4 * i + 2] = b_.z; rv[4 * i + 3] = b_.w;     \
-    }
-#define FC_LSTORE2(ST_)                                                                       \
-    _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                         \
-        const int c_ = tid + 512 * i, kr_ = c_ / CPR, part_ = c_ - kr_ * CPR;                 \
-        *reinterpret_cast<uint4*>(smc + (ST_) * STAGE + kr_ * KP + part_ * 16) =              \
-            make_uint4(rk[4 * i], rk[4 * i + 1], rk[4 * i + 2], rk[4 * i + 3]);               \
-        *reinterpret_cast<uint4*>(smc + (ST_) * STAGE + VOFF + kr_ * VP + part_ * 16) =       \
-            make_uint4(rv[4 * i], rv[4 * i + 1], rv[4 * i + 2], rv[4 * i + 3]);               \
-    }
-#define FC_SLOT_END                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                        \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
-    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0 && nst < 96) p.stamps[grp * 256 + 2 * nst] = __builtin_amdgcn_s_memtime();   \
-    __builtin_amdgcn_s_barrier();                                                             \
-    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0 && nst < 96) p.stamps[grp * 256 + 2 * nst + 1] = __builtin_amdgcn_s_memtime();  \
-    ++nst;                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);
-
-    const int tr_off = (4 * lh + ((lane & 15) >> 2)) * VP + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    const int ntiles = (p.M + 63) / 64;
-    int nst = 0;                                               // slot counter of the diagnostic stamps
-
-    floatx16 s[2];                                             // scores of the tile in flight (S phase -> softmax phase)
-    f16x8 ph[2][2], pl[2][2];                                  // limbs of its probabilities (softmax phase -> P V phase)
-
-    // ---- the three phases of a tile (attn16_kernel's code, cut at the phase boundaries)
-    auto phase_s = [&](int t) __attribute__((always_inline)) {
-        const char* sK = smc + (t & 1) * STAGE;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            floatx16 sm, sc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; }
-            const char* kr = sK + (32 * h2 + li) * KP + 16 * lh;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const f16x8 kh = *reinterpret_cast<const f16x8*>(kr + 32 * ks);
-                const f16x8 kl = *reinterpret_cast<const f16x8*>(kr + 2 * DH + 32 * ks);
-                sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sm, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[h2][r] = fmaf(sc[r], 1.0f / 2048.0f, sm[r]);
-        }
-        if (t * 64 + 64 > p.M) {
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + 32 * h2 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key >= p.M) s[h2][r] = -INFINITY;
-                }
-        }
-    };
-    auto phase_softmax = [&]() __attribute__((always_inline)) {
-        float mt = s[0][0];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[h2][r]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float lt = 0.f;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[h2][r] - m_new);
-                s[h2][r] = pv;
-                lt += pv;
-            }
-        lt += __shfl_xor(lt, 32, 64);
-        l_run = l_run * alpha + lt;
-        m_run = m_new;
-        if (!__all(alpha == 1.0f)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
-#pragma unroll
-                for (int d = 0; d < DT; ++d) { om[d][r] *= ar; oc[d][r] *= ar; }
-            }
-        }
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const float x8[8] = {s[h2][8 * s2], s[h2][8 * s2 + 1], s[h2][8 * s2 + 2], s[h2][8 * s2 + 3],
-                                     s[h2][8 * s2 + 4], s[h2][8 * s2 + 5], s[h2][8 * s2 + 6], s[h2][8 * s2 + 7]};
-                limb_split8(x8, ph[h2][s2], pl[h2][s2]);
-            }
-    };
-    auto phase_pv = [&](int t) __attribute__((always_inline)) {
-        const char* sV = smc + (t & 1) * STAGE + VOFF;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const char* vr = sV + (32 * h2 + 16 * s2) * VP + tr_off;
-#pragma unroll
-                for (int d = 0; d < DT; ++d) {
-#define FC_TR(OFF_) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16*)(vr + (OFF_)))
-                    const f16x8 vh = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(64 * d), FC_TR(8 * VP + 64 * d), 0, 1, 2, 3, 4, 5, 6, 7));
-                    const f16x8 vl = __builtin_bit_cast(f16x8, __builtin_shufflevector(FC_TR(64 * d + 2 * DH), FC_TR(8 * VP + 64 * d + 2 * DH),
-                                                                                      0, 1, 2, 3, 4, 5, 6, 7));
-#undef FC_TR
-                    om[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[h2][s2], vh, om[d], 0, 0, 0);
-                    oc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[h2][s2], vl, oc[d], 0, 0, 0);
-                    oc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[h2][s2], vh, oc[d], 0, 0, 0);
-                }
-            }
-        }
-    };
-
-    FC_GLOAD2(0)
-    FC_LSTORE2(0)
-    FC_SLOT_END
-
-    // one loop per group (same barrier count in both): with the two roles as branches inside ONE loop body the compiler kept the other
-    // role's values (scores, probability limbs) alive through every phase -- 256 registers and 488 bytes of scratch per lane
-    if (grp == 0) {
-        for (int t = 0; t < ntiles; ++t) {
-            const int tn = t + 1 < ntiles ? t + 1 : t;      // the last iteration re-loads its own tile: branch-free staging
-            FC_GLOAD2(tn)
-            phase_s(t);                                     // slot 1
-            FC_SLOT_END
-            phase_softmax();                                // slot 2
-            FC_SLOT_END
-            phase_pv(t);                                    // slot 3
-            FC_LSTORE2((t + 1) & 1)
-            FC_SLOT_END
-        }
-    } else {
-        for (int t = 0; t < ntiles; ++t) {
-            const int tn = t + 1 < ntiles ? t + 1 : t;
-            FC_GLOAD2(tn)
-            if (t > 0) phase_pv(t - 1);                     // slot 1
-            FC_SLOT_END
-            phase_s(t);                                     // slot 2
-            FC_SLOT_END
-            phase_softmax();                                // slot 3
-            FC_LSTORE2((t + 1) & 1)
-            FC_SLOT_END
-        }
-        phase_pv(ntiles - 1);
-    }
-#undef FC_GLOAD2
-#undef FC_LSTORE2
-#undef FC_SLOT_END
-
-    if (p.lse && lane < 32 && q0 + lane < p.N)
-        p.lse[(size_t)b * p.n_stride + q0 + lane] = (m_run + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int qr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float lr = __shfl(l_run, qr, 64);
-        const int qi = q0 + qr;
-        if (qi < p.N) {
-            float* op = p.out + ((size_t)b * p.n_stride + qi) * p.ldo + li;
-#pragma unroll
-            for (int d = 0; d < DT; ++d) op[32 * d] = (om[d][r] + oc[d][r] * (1.0f / 2048.0f)) / lr;
-        }
-    }
-}
-
-extern int g_gemm_stamp;
-unsigned long long* gemm_stamp_buffer(size_t n);
-int g_attn_stagger = 0;      // knob 30: 1 = the 512-thread kernel with two staggered wave groups where a scene has at least 256 queries, 0 = attn16_kernel (shipped:
-                             // same bits, and the stagger measured no gain - 26.58 vs 26.21 ms per C2 step, profiles/r04r_attn_stamps.log has the slot timings)
+// (Round 4 also tried this attention as ONE 512-thread workgroup of two wave groups that run S / softmax / P V one slot apart -- the
+//  explicit matrix | vector alternation of the fused spline GEMM.  Bit-identical and no faster, 26.6 against 26.2 ms per C2 step: the
+//  softmax is VALU issue time that two waves per SIMD need more of than of MFMA time under any interleaving.  The kernel was removed when
+//  this one went to a single accumulator; its measurements stay in DESIGN.md section 9 and profiles/r04q_*, r04r_attn_stamps.log.)
 
 template <int DH>
 static void launch_attn16_dh(const Attn16Params& p, int B, hipStream_t s) {
@@ -709,20 +463,6 @@ static void launch_attn16_dh(const Attn16Params& p, int B, hipStream_t s) {
     attr_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); return 0; });
     char name[64];
     snprintf(name, sizeof name, "void fc::attn16_kernel<%d>(fc::Attn16Params)", DH);
-    // the choice depends on the SCENE's query count only (never on the batch): both kernels give the same bits anyway
-    if (g_attn_stagger && p.N >= 256) {
-        Attn16Params p2 = p;
-        if (g_gemm_stamp == 5) { p2.stamps = gemm_stamp_buffer(512); FC_HIP(hipMemsetAsync(p2.stamps, 0, 512 * sizeof(unsigned long long), s)); }
-        static PerDeviceOnce attr2_once;
-        auto kern2 = attn16x2_kernel<DH>;
-        attr2_once.run([&](int) { FC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); return 0; });
-        char name2[64];
-        snprintf(name2, sizeof name2, "void fc::attn16x2_kernel<%d>(fc::Attn16Params)", DH);
-        ProfScope ps2(name2, 4.0 * B * (double)p.N * (double)p.M * DH, 0.0, s);
-        hipLaunchKernelGGL(kern2, dim3((p.N + 255) / 256, B), dim3(512), lds, s, p2);
-        FC_HIP(hipGetLastError());
-        return;
-    }
     ProfScope ps(name, 4.0 * B * (double)p.N * (double)p.M * DH, 0.0, s);
     hipLaunchKernelGGL(kern, dim3((p.N + 127) / 128, B), dim3(256), lds, s, p);
     FC_HIP(hipGetLastError());

@@ -766,7 +766,8 @@ static Prep prepare(fc_flow& f, const float* ctx, const float* extra, int B, int
         w.kv_limbs = gemm_limb_chain_ok() && attention_fp16_enabled() && d.I_pad <= 64 && f.kv_all.W2 != nullptr && w.ldkv % 128 == 0 && w.ldkv == f.kv_all.N_pad;
         GemmEpi e{};
         e.rows_valid = w.Pc;
-        if (w.kv_limbs) e.C16 = reinterpret_cast<unsigned short*>(w.kv); else { e.C = w.kv; e.ldc = w.ldkv; }
+        if (w.kv_limbs) { e.C16 = reinterpret_cast<unsigned short*>(w.kv); e.c16_scale = kOneAccActScale; }      // (the one-accumulator image the attention kernel multiplies)
+        else { e.C = w.kv; e.ldc = w.ldkv; }
         ASeg a{w.ctxp, d.E_pad};
         launch_gemm(f.kv_all, &a, w.Pc_pad, e, EPI_LINEAR, s);
     }

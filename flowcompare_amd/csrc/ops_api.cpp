@@ -17,7 +17,7 @@ struct TmpBuf {
 }  // namespace fc
 
 
-namespace fc { void one_acc_gemm_debug(const float*, const float*, const float*, float, float*, int, int, int, hipStream_t); long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; extern int g_spline_wide_dma; extern int g_spline_wide_colgroup; extern int g_linear_wide; extern int g_attn_stagger; extern int g_knn_warm; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
+namespace fc { void one_acc_gemm_debug(const float*, const float*, const float*, float, float*, int, int, int, hipStream_t); long gemm_fp16_fallbacks(); extern int g_train_wgrad16; extern int g_train_attn16; extern int g_gemm_dma; extern int g_spline_ablate; extern int g_gemm_dma_linear; extern int g_limb_chain_all; extern int g_gemm_prefetch3; extern int g_premlp_chain; extern int g_gemm_stamp; extern int g_gemm_small_tiles; extern int g_spline_prefetch; extern int g_mlp_rows; extern int g_knn_mfma; extern int g_premlp_lu; extern int g_spline_wide_dma; extern int g_spline_wide_colgroup; extern int g_linear_wide; extern int g_knn_warm; size_t gemm_read_stamps(unsigned long long*, size_t); void flow_set_trace(float*, size_t); }
 namespace fc { extern int g_gemm_variant, g_gemm_colgroup, g_gemm_bigtile, g_attn_fp16, g_fused_spline, g_premlp_fused, g_limb_chain, g_lnq_fold; }
 
 extern "C" {
@@ -51,7 +51,7 @@ int fc_debug_set(int32_t key, int32_t value) {
     else if (key == 29) fc::g_linear_wide = value;       /* hidden layers of the coupling MLP on the 256 x 256 one-accumulator kernel: 0 = off (default: measured no faster than the chain), 1 = for scenes of >= 2048 target points, 2 = at any size */
     else if (key == 32) fc::g_knn_warm = value;         /* 1 = DGCNN levels 1-3 start their k-NN stream from the previous level's neighbour sets (default; exact either way), 0 = from -inf */
     else if (key == 31) fc::g_train_wide = value;       /* 1 = training Linear layers with >= 1024 outputs (the spline parameter layer) on the 256 x 256 one-accumulator loop (default), 0 = on the fp32-A 128 x 128 loop, 3 = 1 with non-temporal stores of a GB-sized output (measured slower) */
-    else if (key == 30) fc::g_attn_stagger = value;     /* 1 = split-fp16 attention as one 512-thread workgroup of two staggered wave groups, 0 = the four-wave kernel (default); bit-identical */
+    else if (key == 30) { if (value != 0) return FC_ERR_UNSUPPORTED; }      /* (was: attention as two staggered wave groups -- measured no faster, removed with the one-accumulator attention kernel) */
     else if (key == 28) fc::g_spline_wide_colgroup = value;   /* column-group size of its tile order (-1 = shipped) */
     else if (key == 20) fc::g_gemm_stamp = value;        /* diagnostic: in-kernel phase stamps of the LDS-DMA fused-spline launches */
     else if (key == 14) fc::g_spline_ablate = value;     /* diagnostic: 1 = fused spline epilogue without the spline evaluation, 2 = main loop only (results invalid) */

