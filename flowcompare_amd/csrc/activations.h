@@ -8,7 +8,7 @@ namespace fc {
 
 // Exact (erf) GELU in one branch-free chain: gelu(v) = v Phi(v), Phi(-|v|) = erfc(u)/2 with u = |v|/sqrt(2), and
 // log2 erfc(u) = -u^2 log2(e) + log2 erfcx(u), where log2 erfcx is smooth and slowly varying (0 ... -3.3 on [0, 5.2]) and is fitted
-// by a degree-11 polynomial (Chebyshev fit, profiles/micro/fit_gelu.py).  20 VALU instructions instead of the 28 of the two-branch erf fit it replaced -- the GEMM epilogues and the fused pre-attention kernel are VALU-bound (PMC: 8-12 VALU instructions per MFMA).
+// by a degree-11 polynomial (Chebyshev fit, profiles/micro/fit_gelu.py).  16 VALU instructions (round 4; 20 before the exponent's - u^2 log2 e was folded into the polynomial and the last two operations into one fma: same 2.4e-7 maximum error, profiles/micro/fit_gelu.py) instead of the 28 of the two-branch erf fit it replaced -- the GEMM epilogues and the fused pre-attention kernel are VALU-bound (PMC: 8-12 VALU instructions per MFMA).
 // fp32 accuracy against fp64: |error| <= 2.4e-7 (half an ulp of v at |v| ~ 5), 9.8e-8 relative to max(1, |v|), and 5e-6 RELATIVE
 // in the negative tail, where the two-branch form lost all relative accuracy (1 - (1 - e^q)).
 __device__ __forceinline__ float fc_gelu(float v) {
@@ -22,12 +22,11 @@ __device__ __forceinline__ float fc_gelu(float v) {
     g = fmaf(g, u, -0.00129302020650357f);
     g = fmaf(g, u, 0.02910642884671688f);
     g = fmaf(g, u, -0.14908140897750854f);
-    g = fmaf(g, u, 0.5244691371917725f);
+    g = fmaf(g, u, 0.5244691371917725f - 1.4426950408889634f);                       // (the - u^2 log2 e of erfc = erfcx e^{-u^2} rides in the u^2 coefficient: round 4, two instructions fewer)
     g = fmaf(g, u, -1.627930760383606f);
     g = fmaf(g, u, 4.18458824924528e-07f - 1.0f);                                    // (- 1: the 1/2 of Phi(-|v|) = erfc(u) / 2 in the log2 domain)
-    const float e = __builtin_amdgcn_exp2f(fmaf(-1.4426950408889634f * u, u, g));      // erfc(u) / 2
-    const float h = v * e;                                                            // v Phi(-|v|), signed like v
-    return fmaxf(v, 0.f) - fabsf(h);                                                   // = v > 0 ? v - h : h (up to the sign of a zero), without compare + select
+    const float e = __builtin_amdgcn_exp2f(g);                                        // erfc(u) / 2
+    return fmaf(-fabsf(v), e, fmaxf(v, 0.f));                                         // = v > 0 ? v - v e : v e, without compare + select (round 4: one fma instead of multiply + subtract)
 }
 
 // Two values -> their packed fp16 limb words: hi = [rn16(x0) | rn16(x1) << 16], lo = [rn16((x0 - hi0) * 2048) |

@@ -264,7 +264,8 @@ void mlp_rows_kernel(const MlpRowsParams p) {
             static_assert(ACT == FC_ACT_GELU, "the interleaved epilogue is written for the exact-erf GELU of the shipped configurations");
             constexpr float C[12] = {3.599303965984291e-08f, -1.1551159104783437e-06f, 1.6193846022360958e-05f, -0.00012855215754825622f,
                                      0.0006109004025347531f, -0.0014898879453539848f, -0.00129302020650357f, 0.02910642884671688f,
-                                     -0.14908140897750854f, 0.5244691371917725f, -1.627930760383606f, 4.18458824924528e-07f};
+                                     -0.14908140897750854f, 0.5244691371917725f - 1.4426950408889634f, -1.627930760383606f, 4.18458824924528e-07f};
+            // (C[9] carries the exponent's - u^2 log2 e, as in fc_gelu)
             // (MR_PIN: an empty volatile asm over a step's results.  The steps are pure arithmetic on registers: nothing else ties them to their
             // slot, and instruction selection otherwise emits all 24 of them in front of the stage's first MFMA.)
 #define MR_PIN(X_) asm volatile("" : "+v"(X_))
@@ -296,20 +297,18 @@ void mlp_rows_kernel(const MlpRowsParams p) {
                     eg[Q][t] = gp;
                 } else if constexpr (hs == 5) {
                     float gp = fmaf(eg[Q][t], eu[Q][t], C[11] - 1.0f);        // (- 1: erfc(u) / 2 in the log2 domain, activations.h)
-                    gp = fmaf(-1.4426950408889634f * eu[Q][t], eu[Q][t], gp);
                     MR_PIN(gp);
                     eg[Q][t] = gp;
                 } else if constexpr (hs == 6) {
                     float e = __builtin_amdgcn_exp2f(eg[Q][t]);                // erfc(u) / 2
-                    float h = ev[Q][t] * e;                                    // v Phi(-|v|), signed like v
-                    MR_PIN(h);
-                    eg[Q][t] = h;
+                    MR_PIN(e);
+                    eg[Q][t] = e;
                 } else if constexpr (hs == 7) {
-                    // fc_gelu's max(v, 0) - |h|; the maximum as asm: behind MR_PIN the compiler no longer knows that v is canonical and puts a
-                    // v_max v, v, v in front of fmaxf
+                    // fc_gelu's fma(-|v|, e, max(v, 0)); the maximum as asm: behind MR_PIN the compiler no longer knows that v is canonical and
+                    // puts a v_max v, v, v in front of fmaxf
                     float m;
                     asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(ev[Q][t]));
-                    float r = m - fabsf(eg[Q][t]);
+                    float r = fmaf(-fabsf(ev[Q][t]), eg[Q][t], m);
                     MR_PIN(r);
                     ev[Q][t] = r;
                 } else if constexpr (hs == 8) {
