@@ -6,27 +6,30 @@
 
 namespace fc {
 
-// Exact (erf) GELU in one branch-free chain: gelu(v) = v Phi(v), Phi(-|v|) = erfc(u)/2 with u = |v|/sqrt(2), and
-// log2 erfc(u) = -u^2 log2(e) + log2 erfcx(u), where log2 erfcx is smooth and slowly varying (0 ... -3.3 on [0, 5.2]) and is fitted
-// by a degree-11 polynomial (Chebyshev fit, profiles/micro/fit_gelu.py).  16 VALU instructions (round 4; 20 before the exponent's - u^2 log2 e was folded into the polynomial and the last two operations into one fma: same 2.4e-7 maximum error, profiles/micro/fit_gelu.py) instead of the 28 of the two-branch erf fit it replaced -- the GEMM epilogues and the fused pre-attention kernel are VALU-bound (PMC: 8-12 VALU instructions per MFMA).
-// fp32 accuracy against fp64: |error| <= 2.4e-7 (half an ulp of v at |v| ~ 5), 9.8e-8 relative to max(1, |v|), and 5e-6 RELATIVE
+// Exact (erf) GELU in one branch-free chain: gelu(v) = v Phi(v), Phi(-|v|) = erfc(|v| / sqrt 2) / 2 = exp2(g(|v|)) with
+// g(w) = log2 erfcx(w / sqrt 2) - (w^2 / 2) log2 e - 1: erfcx is smooth and slowly varying, so g is a parabola plus a small smooth term and is fitted
+// by ONE degree-11 polynomial in w = min(|v|, 7.354) (Chebyshev fit, profiles/micro/fit_gelu.py).  15 VALU instructions: min, 11 fma, exp2, max, fma
+// (round 4; the two-branch erf fit of round 1 took 28, round 3's form of this chain 20: the exponent's - u^2 log2 e and the 1/2 now ride in the
+// polynomial, the argument is |v| itself instead of |v| / sqrt 2, and v - v e is one fma) -- the GEMM epilogues and the row-resident chains are
+// VALU-bound (PMC: 7-12 VALU instructions per MFMA).
+// fp32 accuracy against fp64: |error| <= 2.4e-7 (half an ulp of v at |v| ~ 5), 1.0e-7 relative to max(1, |v|), and 3.3e-6 RELATIVE
 // in the negative tail, where the two-branch form lost all relative accuracy (1 - (1 - e^q)).
 __device__ __forceinline__ float fc_gelu(float v) {
-    const float u = fminf(fabsf(v) * 0.70710678118654752440f, 5.2f);
-    float g = 3.599303965984291e-08f;
-    g = fmaf(g, u, -1.1551159104783437e-06f);
-    g = fmaf(g, u, 1.6193846022360958e-05f);
-    g = fmaf(g, u, -0.00012855215754825622f);
-    g = fmaf(g, u, 0.0006109004025347531f);
-    g = fmaf(g, u, -0.0014898879453539848f);
-    g = fmaf(g, u, -0.00129302020650357f);
-    g = fmaf(g, u, 0.02910642884671688f);
-    g = fmaf(g, u, -0.14908140897750854f);
-    g = fmaf(g, u, 0.5244691371917725f - 1.4426950408889634f);                       // (the - u^2 log2 e of erfc = erfcx e^{-u^2} rides in the u^2 coefficient: round 4, two instructions fewer)
-    g = fmaf(g, u, -1.627930760383606f);
-    g = fmaf(g, u, 4.18458824924528e-07f - 1.0f);                                    // (- 1: the 1/2 of Phi(-|v|) = erfc(u) / 2 in the log2 domain)
-    const float e = __builtin_amdgcn_exp2f(g);                                        // erfc(u) / 2
-    return fmaf(-fabsf(v), e, fmaxf(v, 0.f));                                         // = v > 0 ? v - v e : v e, without compare + select (round 4: one fma instead of multiply + subtract)
+    const float w = fminf(fabsf(v), 7.353910524340095f);
+    float g = 7.953413483363647e-10f;
+    g = fmaf(g, w, -3.609737220244824e-08f);
+    g = fmaf(g, w, 7.156736501201522e-07f);
+    g = fmaf(g, w, -8.034509846766014e-06f);
+    g = fmaf(g, w, 5.399647488957271e-05f);
+    g = fmaf(g, w, -0.0001862359931692481f);
+    g = fmaf(g, w, -0.0002285758382640779f);
+    g = fmaf(g, w, 0.00727660721167922f);
+    g = fmaf(g, w, -0.05270823836326599f);
+    g = fmaf(g, w, -0.4591129422187805f);
+    g = fmaf(g, w, -1.151120901107788f);
+    g = fmaf(g, w, -0.9999995827674866f);
+    const float e = __builtin_amdgcn_exp2f(g);                                        // Phi(-|v|)
+    return fmaf(-fabsf(v), e, fmaxf(v, 0.f));                                         // = v > 0 ? v - v e : v e, without compare + select
 }
 
 // Two values -> their packed fp16 limb words: hi = [rn16(x0) | rn16(x1) << 16], lo = [rn16((x0 - hi0) * 2048) |
@@ -43,13 +46,12 @@ __device__ __forceinline__ void limb_split2(float x0, float x1, unsigned& hi, un
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(lo) : "v"(d1), "s"(2048.0f));
 }
 // One-accumulator form (common.h): hi = rn16(x), lo = rn16(x - hi) UNSCALED (the caller has scaled x so that lo stays a normal number where
-// it matters).  Four VALU instructions for the pair.
+// it matters).  Three VALU instructions for the pair: x - hi is exact in fp32 (hi is x's leading 11 bits), so v_fma_mixlo / mixhi_f16 round it
+// to fp16 once, straight into the two halves of lo -- the bits of subtracting in fp32 and converting the pair (four instructions until round 4).
 __device__ __forceinline__ void limb_split2u(float x0, float x1, unsigned& hi, unsigned& lo) {
-    float d0, d1;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(x0), "v"(x1));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hi), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hi), "v"(x1));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(x1));
 }
 // The same with run-time (wave-uniform) scales: hi = rn16(x s1), lo = rn16((x s1 - hi) s2).  (1, 2048) gives limb_split2's bits exactly (the
 // products by 1 are exact); (kOneAccActScale, 1) the one-accumulator form of spline_wide.hip (common.h).  Six VALU instructions for the pair.

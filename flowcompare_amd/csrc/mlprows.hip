@@ -262,10 +262,7 @@ void mlp_rows_kernel(const MlpRowsParams p) {
         auto epi_step = [&](const floatx16& pa, const floatx16& pc, auto g_tag, auto m_tag) __attribute__((always_inline)) {
             constexpr int g = decltype(g_tag)::value, m = decltype(m_tag)::value, pr = m / 12, hs = m % 12, Q = g & 1;
             static_assert(ACT == FC_ACT_GELU, "the interleaved epilogue is written for the exact-erf GELU of the shipped configurations");
-            constexpr float C[12] = {3.599303965984291e-08f, -1.1551159104783437e-06f, 1.6193846022360958e-05f, -0.00012855215754825622f,
-                                     0.0006109004025347531f, -0.0014898879453539848f, -0.00129302020650357f, 0.02910642884671688f,
-                                     -0.14908140897750854f, 0.5244691371917725f - 1.4426950408889634f, -1.627930760383606f, 4.18458824924528e-07f};
-            // (C[9] carries the exponent's - u^2 log2 e, as in fc_gelu)
+            constexpr float C[12] = {7.953413483363647e-10f, -3.609737220244824e-08f, 7.156736501201522e-07f, -8.034509846766014e-06f, 5.399647488957271e-05f, -0.0001862359931692481f, -0.0002285758382640779f, 0.00727660721167922f, -0.05270823836326599f, -0.4591129422187805f, -1.151120901107788f, -0.9999995827674866f};      // fc_gelu's polynomial in w = min(|v|, 7.354), highest degree first
             // (MR_PIN: an empty volatile asm over a step's results.  The steps are pure arithmetic on registers: nothing else ties them to their
             // slot, and instruction selection otherwise emits all 24 of them in front of the stage's first MFMA.)
 #define MR_PIN(X_) asm volatile("" : "+v"(X_))
@@ -285,7 +282,7 @@ void mlp_rows_kernel(const MlpRowsParams p) {
                     MR_PIN(v);
                     ev[Q][t] = v;
                 } else if constexpr (hs == 1) {
-                    float u = fminf(fabsf(ev[Q][t]) * 0.70710678118654752440f, 5.2f);
+                    float u = fminf(fabsf(ev[Q][t]), 7.353910524340095f);
                     float gp = fmaf(C[0], u, C[1]);
                     MR_PIN(u); MR_PIN(gp);
                     eu[Q][t] = u; eg[Q][t] = gp;
@@ -296,7 +293,7 @@ void mlp_rows_kernel(const MlpRowsParams p) {
                     MR_PIN(gp);
                     eg[Q][t] = gp;
                 } else if constexpr (hs == 5) {
-                    float gp = fmaf(eg[Q][t], eu[Q][t], C[11] - 1.0f);        // (- 1: erfc(u) / 2 in the log2 domain, activations.h)
+                    float gp = fmaf(eg[Q][t], eu[Q][t], C[11]);
                     MR_PIN(gp);
                     eg[Q][t] = gp;
                 } else if constexpr (hs == 6) {

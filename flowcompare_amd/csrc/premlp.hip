@@ -311,6 +311,13 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = blockIdx.x * PR_ROWS + wave * 16 + n;
     float amax = 0.f;
+    // Lane constants of the swizzled weight-fragment reads (round 4).  A lane reads 16-byte chunk (ch ^ sw) of its weight row with ch = 8 s + kgp
+    // (k step s, hi limb; lo' = ch + 2) and sw = n (rows of 64 or 80 chunks) or n & 7 (40 chunks).  kgp = {0, 1, 4, 5} has bit 1 clear, so the
+    // XOR splits: low three bits kgp ^ (n & 7) (lo': the same ^ 2), and -- four-bit swizzle only -- k steps 2 j and 2 j + 1 change places in rows
+    // with bit 3 set.  Hence four bases per chunk and compile-time offsets 256 j + 16 KB mb instead of one address computation per read
+    // (38 v_add_u32 per chunk of 48 MFMAs in a kernel bound by what its waves issue).
+    const int pr_off3 = ((4 * (kg >> 1) + (kg & 1)) ^ (n & 7)) * 16;
+    const int pr_off4 = pr_off3 + 128 * ((n >> 3) & 1);
 
 #define PR_STAMP(K_)                                                                                                  \
     if (p.stamps && threadIdx.x == 0) {                                                                               \
@@ -402,6 +409,31 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
         grp ^= 1;
         after_dma();                                                    // (loads that must not sit in front of the wait above: they get this chunk's time to land)
+        if constexpr (KSTAT > 0) {
+            // compile-time row length (K = 32 KSTAT: launch_premlp instantiates KSIN = 5 for K_pad 160 only, the other layers are 256 wide)
+            constexpr int CPR = KSTAT * 8;
+            constexpr bool SW4 = (CPR & 15) == 0;
+            const char* wb = smc + buf * PRB + n * (CPR * 16);
+            const int o = SW4 ? pr_off4 : pr_off3;
+            const char* bh0 = wb + o;
+            const char* bl0 = wb + (o ^ 32);
+            const char* bh1 = wb + (SW4 ? (o ^ 128) : o + 128);          // odd k steps
+            const char* bl1 = wb + (SW4 ? (o ^ 160) : (o ^ 32) + 128);
+#pragma unroll
+            for (int s_ = 0; s_ < KSTAT; ++s_) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const int imm = 256 * (s_ >> 1) + mb * 16 * CPR * 16;
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(((s_ & 1) ? bh1 : bh0) + imm);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(((s_ & 1) ? bl1 : bl0) + imm);
+                    am[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[s_], am[mb], 0, 0, 0);
+                    ac[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[s_], ac[mb], 0, 0, 0);
+                    ac[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[s_], ac[mb], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+            return;
+        }
         const int cpr = L.K_pad >> 2, KS = L.K_pad >> 5;
         const int sw = (cpr & 15) == 0 ? n : (n & 7);
         const char* wrow = smc + buf * PRB + n * cpr * 16;
@@ -424,10 +456,10 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     };
     // accumulator order (block mb, register i = feature 16 mb + 4 kg + i) -> operand order: t[e] = out-feature 32 c + 8 kg + e (before bias)
     auto fold = [&](const floatx4 (&am)[2], const floatx4 (&ac)[2], float (&t)[8]) __attribute__((always_inline)) {
-        float P0 = am[0][0] + ac[0][0] * (1.0f / 2048.0f), P1 = am[0][1] + ac[0][1] * (1.0f / 2048.0f);
-        float P2 = am[0][2] + ac[0][2] * (1.0f / 2048.0f), P3 = am[0][3] + ac[0][3] * (1.0f / 2048.0f);
-        float Q0 = am[1][0] + ac[1][0] * (1.0f / 2048.0f), Q1 = am[1][1] + ac[1][1] * (1.0f / 2048.0f);
-        float Q2 = am[1][2] + ac[1][2] * (1.0f / 2048.0f), Q3 = am[1][3] + ac[1][3] * (1.0f / 2048.0f);
+        // (am + ac / 2048 as ONE fma each: the scaling by a power of two is exact, so the sum rounds once either way -- the bits of multiply + add)
+        constexpr float F = 1.0f / 2048.0f;
+        float P0 = fmaf(ac[0][0], F, am[0][0]), P1 = fmaf(ac[0][1], F, am[0][1]), P2 = fmaf(ac[0][2], F, am[0][2]), P3 = fmaf(ac[0][3], F, am[0][3]);
+        float Q0 = fmaf(ac[1][0], F, am[1][0]), Q1 = fmaf(ac[1][1], F, am[1][1]), Q2 = fmaf(ac[1][2], F, am[1][2]), Q3 = fmaf(ac[1][3], F, am[1][3]);
         // the eight lane swaps as one block: two wait states between a VALU write and the first swap that reads it; a pair's
         // permlane16 swap stands three instructions behind its permlane32 swap
         asm volatile("s_nop 1\n\t"
@@ -442,14 +474,17 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     // streamed 90 KB of instructions once per workgroup through a 64 KB instruction cache).  Flags are compile-time: straight-line
     // code the scheduler lays under the NEXT chunk's MFMAs (8 values x ~35 VALU instructions per lane and chunk are as much issue time
     // as the chunk's 48 MFMAs).
-    auto epilogue = [&](const float (&t)[8], const f16x8& rh, const f16x8& rl, int bias_off, auto resid_tag, auto act_tag) __attribute__((always_inline)) {
+    auto epilogue = [&](const float (&t)[8], const f16x8& rh, const f16x8& rl, int bias_off, auto resid_tag, auto act_tag, auto shift_tag, auto slot_tag) __attribute__((always_inline)) {
         constexpr bool RESID = decltype(resid_tag)::value;
         constexpr int A = decltype(act_tag)::value;
+        constexpr int SHIFT = decltype(shift_tag)::value, SLOT = decltype(slot_tag)::value;      // the FIFO moves up by SHIFT slots, then slot SLOT is written
         const float* bp = biasbuf + bias_off + 8 * kg;
         const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
         const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        if constexpr (SHIFT > 0) {
 #pragma unroll
-        for (int b = 0; b < 7; ++b) { nh[b] = nh[b + 1]; nl[b] = nl[b + 1]; }
+            for (int b = 0; b + SHIFT < 8; ++b) { nh[b] = nh[b + SHIFT]; nl[b] = nl[b + SHIFT]; }
+        }
         float res[8], xv[8];
         if constexpr (RESID) limb_join8(rh, rl, res);                   // (one v_fma_mix_f32 per value, activations.h)
 #pragma unroll
@@ -463,7 +498,7 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             amax = fmaxf(amax, fabsf(x));
             xv[e] = x;
         }
-        limb_split8(xv, nh[7], nl[7]);                                  // (five instructions per pair of values)
+        limb_split8(xv, nh[SLOT], nl[SLOT]);                            // (five instructions per pair of values)
     };
     // one layer, software-pipelined: iteration c issues the MFMAs of chunk c and, behind them in the same basic block, the epilogue of
     // chunk c - 1 (iteration 0 pushes a dummy that the eight real pushes shift out again)
@@ -473,8 +508,9 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         f16x8 rph, rpl, rch, rcl;                                       // residual fragments of the previous / this chunk
 #pragma unroll
         for (int e = 0; e < 8; ++e) { tp[e] = 0.f; rph[e] = 0; rpl[e] = 0; rch[e] = 0; rcl[e] = 0; }
-#pragma unroll 1
-        for (int c = 0; c < 8; ++c) {
+        // (round 4: the loop body is a PAIR of chunks and the FIFO moves by two slots per pair -- 12 fragment moves per pair instead of 14 per chunk;
+        //  8 KB of code per layer instead of 4.  Pushes: [dummy, 0] [1, 2] [3, 4] [5, 6] into slots 6 and 7, then chunk 7 behind a move by one.)
+        auto one = [&](int c, auto shift_tag, auto slot_tag) __attribute__((always_inline)) {
             floatx4 am[2], ac[2];
             chunk_mma(L, c + 1 < 8 ? &L : &nextL, c + 1 < 8 ? c + 1 : 0, fullk_tag, am, ac, [&]() __attribute__((always_inline)) {
                 if constexpr (RESID) {
@@ -482,11 +518,16 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     rcl = __builtin_bit_cast(f16x8, keep_frag[(2 * c + 1) * PR_NT]);
                 }
             });
-            epilogue(tp, rph, rpl, lidx * PM_H + 32 * (c > 0 ? c - 1 : 0), resid_tag, act_tag);
+            epilogue(tp, rph, rpl, lidx * PM_H + 32 * (c > 0 ? c - 1 : 0), resid_tag, act_tag, shift_tag, slot_tag);
             fold(am, ac, tp);
             rph = rch; rpl = rcl;
+        };
+#pragma unroll 1
+        for (int c = 0; c < 8; c += 2) {
+            one(c, std::integral_constant<int, 2>{}, std::integral_constant<int, 6>{});
+            one(c + 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 7>{});
         }
-        epilogue(tp, rph, rpl, lidx * PM_H + 32 * 7, resid_tag, act_tag);
+        epilogue(tp, rph, rpl, lidx * PM_H + 32 * 7, resid_tag, act_tag, std::integral_constant<int, 1>{}, std::integral_constant<int, 7>{});
 #pragma unroll
         for (int b = 0; b < 8; ++b) { ah[b] = nh[b]; al[b] = nl[b]; }
     };
@@ -520,16 +561,20 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             else pr_dma(p.in, 0, smc + (buf ^ 1) * PRB, wave, lane, grp);
             grp ^= 1;
             constexpr int cpr = NLU * 8;                                    // 16-byte chunks per weight row
-            const int sw = (cpr & 15) == 0 ? n : (n & 7);
-            const char* wrow = smc + buf * PRB + n * cpr * 16;
+            constexpr bool SW4 = (cpr & 15) == 0;
+            const char* wb = smc + buf * PRB + n * (cpr * 16);              // (bases + compile-time offsets: see pr_off3 / pr_off4)
+            const int o = SW4 ? pr_off4 : pr_off3;
+            const char* bh0 = wb + o;
+            const char* bl0 = wb + (o ^ 32);
+            const char* bh1 = wb + (SW4 ? (o ^ 128) : o + 128);
+            const char* bl1 = wb + (SW4 ? (o ^ 160) : (o ^ 32) + 128);
 #pragma unroll
             for (int s_ = 0; s_ < NLU; ++s_) {
-                const int ch = 4 * (2 * s_ + (kg >> 1)) + (kg & 1);
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
-                    const char* wr = wrow + mb * 16 * cpr * 16;
-                    const f16x8 wh = *reinterpret_cast<const f16x8*>(wr + ((ch) ^ sw) * 16);
-                    const f16x8 wl = *reinterpret_cast<const f16x8*>(wr + ((ch + 2) ^ sw) * 16);
+                    const int imm = 256 * (s_ >> 1) + mb * 16 * cpr * 16;
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(((s_ & 1) ? bh1 : bh0) + imm);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(((s_ & 1) ? bl1 : bl0) + imm);
                     am[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, uh[s_], am[mb], 0, 0, 0);
                     ac[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, uh[s_], ac[mb], 0, 0, 0);
                     ac[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ul[s_], ac[mb], 0, 0, 0);
