@@ -284,12 +284,17 @@ __device__ __forceinline__ void pr_swap16(float& a, float& b) { asm volatile("s_
 // ~190 cycles: with all eight issuing behind the barrier every SIMD stood for 4 x 190 cycles per chunk; now one wave per SIMD issues
 // (8 pieces) while its partner is already multiplying.
 __device__ __forceinline__ void pr_dma(const PreMlpLayer& L, int c, char* dst, int wave, int lane, int grp) {
+#ifdef FC_PREMLP_DMA_LATE
+    const int first = wave, step = 8;                        // experiment: every wave issues its share, BEHIND its chunk's reads and MFMAs (see chunk_mma)
+#else
     if ((wave >> 2) != grp) return;
+    const int first = wave & 3, step = 4;
+#endif
     const int cpr = L.K_pad >> 2;                            // 16-byte chunks per weight row (64 at K = 256, 40 at K = 160)
     const int sw = (cpr & 15) == 0 ? 15 : 7;
     const int npieces = cpr >> 1;                            // 32 rows * cpr chunks / 64 lanes
     const char* base = reinterpret_cast<const char*>(L.W2) + (size_t)c * PR_CH * cpr * 16;
-    for (int pc = wave & 3; pc < npieces; pc += 4) {
+    for (int pc = first; pc < npieces; pc += step) {
         const int ci = pc * 64 + lane;
         const int r = cpr == 64 ? ci >> 6 : ci / cpr;
         const int q = ci - r * cpr;
@@ -406,7 +411,9 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         PR_WAIT_T1
         __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
         PR_WAIT_T2
+#ifndef FC_PREMLP_DMA_LATE
         if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+#endif
         grp ^= 1;
         after_dma();                                                    // (loads that must not sit in front of the wait above: they get this chunk's time to land)
         if constexpr (KSTAT > 0) {
@@ -431,6 +438,9 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     ac[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, al[s_], ac[mb], 0, 0, 0);
                 }
             }
+#ifdef FC_PREMLP_DMA_LATE
+            if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+#endif
             buf ^= 1;
             return;
         }
@@ -452,6 +462,9 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 }
             }
         }
+#ifdef FC_PREMLP_DMA_LATE
+        if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+#endif
         buf ^= 1;
     };
     // accumulator order (block mb, register i = feature 16 mb + 4 kg + i) -> operand order: t[e] = out-feature 32 c + 8 kg + e (before bias)
@@ -557,8 +570,10 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             PR_WAIT_T1
             __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
             PR_WAIT_T2
+#ifndef FC_PREMLP_DMA_LATE
             if (c + 1 < NLU) pr_dma(p.lu, c + 1, smc + (buf ^ 1) * PRB, wave, lane, grp);
             else pr_dma(p.in, 0, smc + (buf ^ 1) * PRB, wave, lane, grp);
+#endif
             grp ^= 1;
             constexpr int cpr = NLU * 8;                                    // 16-byte chunks per weight row
             constexpr bool SW4 = (cpr & 15) == 0;
@@ -580,6 +595,10 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                     ac[mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ul[s_], ac[mb], 0, 0, 0);
                 }
             }
+#ifdef FC_PREMLP_DMA_LATE
+            if (c + 1 < NLU) pr_dma(p.lu, c + 1, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            else pr_dma(p.in, 0, smc + (buf ^ 1) * PRB, wave, lane, grp);
+#endif
             buf ^= 1;
         };
         auto lu_finish = [&](const float (&t)[8], int c) __attribute__((always_inline)) {       // chunk c >= 0 (wave-uniform)

@@ -270,6 +270,28 @@ def test_attention_spiked_scores_force_rescale():
     assert (out - ref).abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("per_tile", [0.4, 1.5, 7.5])
+def test_attention_lazy_reference_on_score_ramps(per_tile):
+    """Round 4: the split-fp16 attention moves its softmax reference only when a tile's maximum exceeds it by more than 3 (log2 domain), so the
+    probabilities it holds are bounded by 2^3 (csrc/attention.hip, models/perceiver.py:106-113).  Scores that RISE along the key axis by 0.4 / 1.5 /
+    7.5 nats per 64-key tile move the reference every fifth tile / every second tile / every tile, with probabilities above 1 in between:
+    against fp64, to the bound of the exact-maximum form."""
+    B, N, M, D = 2, 200, 1024, 64
+    q, k, v = _rand(B, N, D, seed=61), _rand(B, M, D, seed=62), _rand(B, M, D, seed=63, scale=2.0)
+    q[..., 0] = 4.0                                                          # score = 0.125 q . k: column 0 of k carries the ramp
+    k[..., 0] = torch.arange(M).float()[None, :] * (per_tile / 64.0 / (0.125 * 4.0))
+    ref = torch.softmax((q.double() @ k.double().transpose(1, 2)) * 0.125, -1) @ v.double()
+    lib = engine.lib()
+    lib.fc_debug_fp16_fallbacks.restype = ctypes.c_int64
+    before = lib.fc_debug_fp16_fallbacks()
+    y = engine.op_attention(q.to(DEV), k.to(DEV), v.to(DEV), 0.125).cpu()
+    assert lib.fc_debug_fp16_fallbacks() == before, "the ramp must stay inside fp16's range (this test is about the split-fp16 kernel)"
+    err = (y.double() - ref).abs().max().item()
+    smax = per_tile * M / 64                                                 # a score s is known to |s| 2^-24 in fp32: so is its probability, relatively
+    print(f"ramp {per_tile} nats per tile: max |y - fp64| = {err:.2e}   (largest score {smax:.0f} nats)")
+    assert err < 4e-6 + 2.5e-7 * smax
+
+
 @pytest.fixture(params=[2, 0], ids=["mfma-kernel", "lane-per-candidate-kernel"])
 def knn_kernel(request):
     """Both k-NN kernels (csrc/knn.hip): 2 = the matrix-core kernel forced at any size (the engine picks it where the launch fills the chip),
