@@ -175,18 +175,18 @@ __device__ __forceinline__ void rq_spline_fwd_regs_scaled(float x, const U& u, f
 }
 
 // eight fp32 values (k = 8 kq .. 8 kq + 7 of one point) -> the hi / lo operand fragments of the one-accumulator form, x s = hi + lo with s an
-// exact power of two; amax collects max |x s| (the caller turns it into the range flag).  Five instructions per pair of values (measured issue
+// exact power of two; amax collects max |x s| (the caller turns it into the range flag).  Four instructions per pair of values + the running maximum (measured issue
 // costs on gfx950, profiles/micro/valu_rate_probe.hip: v_pk_mul_f32 6.6, v_cvt_pk_f16_f32 8.1, v_fma_mix_f32 8.4 cycles per wave; the all-mix
 // form of activations.h limb_split2s is six at 8.4 - 9.3).
 typedef float sw_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void sw_split2v(sw_f32x2 x, sw_f32x2 sv, unsigned& hi, unsigned& lo, float& amax) {
     sw_f32x2 t;
-    float d0, d1;
     asm("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(sv));
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(t[0]), "v"(t[1]));
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(d0) : "v"(t[0]), "v"(hi));
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d1) : "v"(t[1]), "v"(hi));
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
+    // (x s - hi is exact in fp32, so v_fma_mixlo / mixhi_f16 round it once, straight into the halves of lo: the bits of the two v_fma_mix_f32 +
+    //  v_cvt_pk_f16_f32 this replaced, one instruction fewer per pair -- activations.h limb_split2u)
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(t[0]), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(t[1]), "v"(hi));
     asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(t[0]), "v"(t[1]));      // (volatile: pins the running maximum; left to hipcc the raw values of a k step are kept for one reduction tree and spill)
 }
 __device__ __forceinline__ void sw_split8(const float4& r0, const float4& r1, float sv, f16x8& hi, f16x8& lo, float& amax) {
