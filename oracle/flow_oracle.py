@@ -22,6 +22,7 @@ Every function cites the reference file:line it restates
 """
 import contextlib
 import math
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -101,7 +102,7 @@ def affine_coupling(sd, prefix, x, cond, act, scale_fn, split=None, inverse=Fals
     return torch.cat((a, b * s + t), -1), torch.log(s).sum(-1)
 
 
-_SPLINE_HOOK = None      # test helper of the full-depth parity tests: spline_decisions() below
+_SPLINE_TLS = threading.local()      # test helper of the full-depth parity tests: spline_decisions() below (per thread: the tests run independent oracle passes side by side)
 
 
 @contextlib.contextmanager
@@ -113,7 +114,6 @@ def spline_decisions(forced=None):
     one passes through with log-det 0.  The spline has derivative 0.6936 at the boundary knots but the identity outside, so log p jumps by
     0.366 nats at |x2| = 3: an fp32 run may land on either side where its latent is within its rounding error of 3, and only the run's
     own decisions make a like-for-like fp64 reference for it."""
-    global _SPLINE_HOOK
     rec, it = [], (iter(forced) if forced is not None else None)
 
     def hook(x, inside):
@@ -121,11 +121,12 @@ def spline_decisions(forced=None):
             inside = next(it).to(torch.bool).reshape(inside.shape)
         rec.append(inside)
         return inside
-    prev, _SPLINE_HOOK = _SPLINE_HOOK, hook
+    prev = getattr(_SPLINE_TLS, "hook", None)
+    _SPLINE_TLS.hook = hook
     try:
         yield rec
     finally:
-        _SPLINE_HOOK = prev
+        _SPLINE_TLS.hook = prev
 
 
 def rq_spline(x, uw, uh, ud, inverse=False, bound=3.0, min_w=1e-3, min_h=1e-3, min_d=1e-3):
@@ -140,8 +141,9 @@ def rq_spline(x, uw, uh, ud, inverse=False, bound=3.0, min_w=1e-3, min_h=1e-3, m
     """
     K = uw.shape[-1]
     inside = (x >= -bound) & (x <= bound)
-    if _SPLINE_HOOK is not None and not inverse:
-        inside = _SPLINE_HOOK(x, inside)                      # (test helper: record / force the decisions; a no-op clamp otherwise)
+    hook = getattr(_SPLINE_TLS, "hook", None)
+    if hook is not None and not inverse:
+        inside = hook(x, inside)                      # (test helper: record / force the decisions; a no-op clamp otherwise)
     xc = torch.where(inside, x.clamp(-bound, bound), torch.zeros_like(x))          # any in-range stand-in for masked lanes
     const = float(torch.tensor(math.log(math.exp((1 - min_d) - 1))))      # the reference builds it as a float32 tensor (:43)
     ud_p = torch.cat((torch.full_like(ud[..., :1], const), ud), -1)      # knots 0..K+1 (last unused)

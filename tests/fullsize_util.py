@@ -105,6 +105,16 @@ def hip_rows_with_decisions(cfg, md, ctx_dev, x, extra, eps):
     return lp[0].cpu(), [((x2[l] >= -3.0) & (x2[l] <= 3.0))[None] for l in range(n_layers)]
 
 
+def side_by_side(*thunks):
+    """Independent oracle passes on threads of their own (they are chains of small CPU tensor operations that leave most host cores idle; the
+    decision recorder of oracle.spline_decisions is per thread): returns the thunks' results in order.  Grad mode is per thread as well --
+    oracle_flow_rows / oracle_flow_rows_forced enter torch.no_grad() themselves."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(thunks)) as ex:
+        futs = [ex.submit(t) for t in thunks]
+        return [f.result() for f in futs]
+
+
 def oracle_flow_rows_forced(cfg, md, ctx, x, extra, eps, dtype, forced=None):
     """oracle_flow_rows with the spline decisions recorded (and, with `forced`, taken from that list instead of the oracle's own latent):
     returns (log_prob [n], the decisions used, one [1, n, d2] mask per layer)."""

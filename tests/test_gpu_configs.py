@@ -17,7 +17,7 @@ import torch
 import flowcompare_amd as fa
 from flowcompare_amd import engine
 from oracle import flow_oracle as O
-from fullsize_util import build_conditioned, check_rows_against_fp64, oracle_flow_rows, state_dicts, synth_pairs
+from fullsize_util import build_conditioned, check_rows_against_fp64, oracle_flow_rows, side_by_side, state_dicts, synth_pairs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -36,8 +36,9 @@ def _rows_vs_oracle(label, cfg, md, e0, e1, extra, eps, lp, n):
     c = dict(cfg)
     c["sample_size"] = n
     t0 = time.time()
-    lp64, margin = oracle_flow_rows(c, md, ctx, e1[:1, :n], ex, [eps[:1, :n]], torch.float64)
-    lp32, _ = oracle_flow_rows(c, md, ctx, e1[:1, :n], ex, [eps[:1, :n]], torch.float32)
+    (lp64, margin), (lp32, _) = side_by_side(                              # the fp64 and the fp32 pass on threads of their own
+        lambda: oracle_flow_rows(c, md, ctx, e1[:1, :n], ex, [eps[:1, :n]], torch.float64),
+        lambda: oracle_flow_rows(c, md, ctx, e1[:1, :n], ex, [eps[:1, :n]], torch.float32))
     print(f"oracle: {time.time() - t0:.0f} s of host time")
     return check_rows_against_fp64(label, lp[0, :n].cpu(), lp64, lp32, margin)
 
@@ -53,9 +54,14 @@ def test_c1_whole_batch_against_the_oracle_in_full():
     sd_f, sd_e = state_dicts(md, torch.float64)
     sf32, se32 = state_dicts(md, torch.float32)
     t0 = time.time()
-    with torch.no_grad():
-        _, lp64, bpd64 = O.inner_loop(cfg, sd_f, sd_e, (e0.double(), e1.double(), None), [eps.double()])
-        _, lp32, _ = O.inner_loop(cfg, sf32, se32, (e0, e1, None), [eps])
+    def pass64():
+        with torch.no_grad():                                              # (grad mode is per thread)
+            return O.inner_loop(cfg, sd_f, sd_e, (e0.double(), e1.double(), None), [eps.double()])
+
+    def pass32():
+        with torch.no_grad():
+            return O.inner_loop(cfg, sf32, se32, (e0, e1, None), [eps])
+    (_, lp64, bpd64), (_, lp32, _) = side_by_side(pass64, pass32)
     print(f"oracle inner_loop (embedder + 115 layers, 2 x 1024 points, fp64 and fp32): {time.time() - t0:.0f} s of host time")
     margin = torch.full((B * N,), float("inf"), dtype=torch.float64)
     check_rows_against_fp64("C1 2 x 1024 x 115 affine layers, global context, whole batch", lp.cpu().reshape(-1), lp64.reshape(-1),

@@ -18,7 +18,7 @@ import torch
 
 import flowcompare_amd as fa
 from oracle import flow_oracle as O
-from fullsize_util import (build_conditioned, check_spline_rows_against_fp64, hip_rows_with_decisions, oracle_flow_rows_forced, state_dicts,
+from fullsize_util import (build_conditioned, check_spline_rows_against_fp64, hip_rows_with_decisions, oracle_flow_rows_forced, side_by_side, state_dicts,
                            synth_pairs)
 
 pytestmark = pytest.mark.gpu
@@ -61,9 +61,10 @@ def test_full_size_rows_match_fp64_oracle_at_golden_gates(c2):
     ctx = ctx_dev.cpu()
     t0 = time.time()
     args = (cfg, md, ctx, e1[:1, :n], None, [eps[:1, :n]])
-    lp64_nat, dec64 = oracle_flow_rows_forced(*args, torch.float64)
-    lp64_hip, _ = oracle_flow_rows_forced(*args, torch.float64, forced=dec_hip)
-    lp32, dec32 = oracle_flow_rows_forced(*args, torch.float32)
+    (lp64_nat, dec64), (lp64_hip, _), (lp32, dec32) = side_by_side(           # three independent passes on threads of their own
+        lambda: oracle_flow_rows_forced(*args, torch.float64),
+        lambda: oracle_flow_rows_forced(*args, torch.float64, forced=dec_hip),
+        lambda: oracle_flow_rows_forced(*args, torch.float32))
     lp64_ref, _ = oracle_flow_rows_forced(*args, torch.float64, forced=dec32)
     print(f"oracle: {time.time() - t0:.0f} s of host time")
     check_spline_rows_against_fp64("C2 16 x 4096 x 115 spline layers, scene 0 rows 0..511", lp_rows, dec_hip, lp64_hip, lp64_nat, dec64, lp32, lp64_ref)
@@ -83,11 +84,14 @@ def test_full_size_rows_match_the_oracle_end_to_end_with_its_own_embedder(c2):
         ctx64 = O.context_embed(cfg, sd_e, e0[:1].double())
     moved = (ctx_dev.cpu().double() - ctx64).abs().amax(-1)[0]
     print(f"context rows whose embedding differs from the fp64 oracle's by more than 1e-4 (k-NN near-ties): {int((moved > 1e-4).sum())} of {moved.numel()}")
-    lp64_hip, _ = oracle_flow_rows_forced(cfg, md, ctx64, e1[:1, :n], None, [eps[:1, :n]], torch.float64, forced=dec_hip)
     _, se32 = state_dicts(md, torch.float32)
-    with torch.no_grad():
-        ctx32 = O.context_embed(cfg, se32, e0[:1])
-    lp32, dec32 = oracle_flow_rows_forced(cfg, md, ctx32, e1[:1, :n], None, [eps[:1, :n]], torch.float32)
+
+    def fp32_pass():
+        with torch.no_grad():
+            ctx32 = O.context_embed(cfg, se32, e0[:1])
+        return oracle_flow_rows_forced(cfg, md, ctx32, e1[:1, :n], None, [eps[:1, :n]], torch.float32)
+    (lp64_hip, _), (lp32, dec32) = side_by_side(
+        lambda: oracle_flow_rows_forced(cfg, md, ctx64, e1[:1, :n], None, [eps[:1, :n]], torch.float64, forced=dec_hip), fp32_pass)
     lp64_ref, _ = oracle_flow_rows_forced(cfg, md, ctx64, e1[:1, :n], None, [eps[:1, :n]], torch.float64, forced=dec32)
     print(f"oracle: {time.time() - t0:.0f} s of host time")
     check_spline_rows_against_fp64("C2 end to end (oracle's own fp64 embedder), scene 0 rows 0..255", lp_rows, dec_hip, lp64_hip, None, None, lp32, lp64_ref, end_to_end=True)

@@ -164,3 +164,34 @@ def test_spline_decision_hook_records_and_forces_without_changing_the_natural_ru
     assert abs(float(yb[0, 0]) - 3.0) < 1e-9 and math.isfinite(float(lb[0, 0]))
     assert float(yb[0, 1]) == float(xb[0, 1]) and float(lb[0, 1]) == 0.0
     assert abs(float(yb[0, 2]) + 3.0) < 1e-9 and abs(float(lb[0, 2]) - jump) < 1e-6
+
+
+def test_spline_decision_hook_is_per_thread():
+    """The full-depth parity tests run independent oracle passes side by side (tests/fullsize_util.py::side_by_side): a thread's recorder /
+    forced decisions must not be seen by another thread's pass."""
+    import threading
+    from oracle import flow_oracle as O
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(64, 7, generator=g, dtype=torch.float64) * 2.5
+    p = [torch.randn(64, 7, n, generator=g, dtype=torch.float64) for n in (8, 8, 9)]
+    y0, l0 = O.rq_spline(x, *p)
+    all_out = torch.zeros(64, 7, dtype=torch.bool)
+    out, start = {}, threading.Barrier(2)
+
+    def natural():
+        start.wait()
+        with O.spline_decisions() as rec:
+            for _ in range(50):
+                y, l = O.rq_spline(x, *p)
+        out["nat"] = (y, l, len(rec))
+
+    def forced():
+        start.wait()
+        with O.spline_decisions(forced=[all_out] * 50) as rec:
+            for _ in range(50):
+                y, l = O.rq_spline(x, *p)
+        out["forced"] = (y, l, len(rec))
+    ts = [threading.Thread(target=natural), threading.Thread(target=forced)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert torch.equal(out["nat"][0], y0) and torch.equal(out["nat"][1], l0) and out["nat"][2] == 50
+    assert torch.equal(out["forced"][0], x) and float(out["forced"][1].abs().max()) == 0.0 and out["forced"][2] == 50
