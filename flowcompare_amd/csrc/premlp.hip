@@ -283,12 +283,37 @@ __device__ __forceinline__ void pr_swap16(float& a, float& b) { asm volatile("s_
 // waves 0..3 for even chunks of the stream, 4..7 for odd ones.  Waves w and w + 4 share a SIMD, and issuing a piece stalls its wave
 // ~190 cycles: with all eight issuing behind the barrier every SIMD stood for 4 x 190 cycles per chunk; now one wave per SIMD issues
 // (8 pieces) while its partner is already multiplying.
+// CPRH: the layer's row length in 16-byte chunks when the call site knows it at compile time (64: the 256-wide layers; 40 / 80: the in_layer at
+// K = 160 / the ActNorm + LU pre-layer at K = 320), 0 = read it from the layer.  Round 4, second half: the general form spends two 64-bit
+// multiply-adds, a division and ~10 more instructions per piece -- about half of the ~190 cycles a piece holds its wave, and the issuing wave's
+// pieces are on the chunk's critical path.  With the row length known a 256-wide row is one piece (lane l reads chunk l ^ (pc & 15) of row pc:
+// one 64-bit add per piece on precomputed lane offsets), and for the other lengths the division is a multiply + shift in 32 bits.
+template <int CPRH>
 __device__ __forceinline__ void pr_dma(const PreMlpLayer& L, int c, char* dst, int wave, int lane, int grp) {
 #ifdef FC_PREMLP_DMA_LATE
     const int first = wave, step = 8;                        // experiment: every wave issues its share, BEHIND its chunk's reads and MFMAs (see chunk_mma)
 #else
     if ((wave >> 2) != grp) return;
     const int first = wave & 3, step = 4;
+    if constexpr (CPRH == 64) {
+        const char* ubase = reinterpret_cast<const char*>(L.W2) + (size_t)c * (PR_CH * 64 * 16) + first * 1024;
+        const unsigned l0 = (unsigned)(lane ^ first) << 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((pm_glb_char*)(ubase + j * 4096 + (l0 ^ (unsigned)((j & 3) << 6))), (pm_lds_char*)(dst + (first + 4 * j) * 1024), 16, 0, 0);
+        return;
+    } else if constexpr (CPRH > 0) {
+        constexpr int SW = (CPRH & 15) == 0 ? 15 : 7, NP = CPRH / 2;
+        static_assert(NP % 4 == 0, "every issuing wave takes the same number of pieces");
+        const char* ubase = reinterpret_cast<const char*>(L.W2) + (size_t)c * (PR_CH * CPRH * 16);
+#pragma unroll
+        for (int j = 0; j < NP / 4; ++j) {
+            const int pc = first + 4 * j;
+            const unsigned ci = (unsigned)(pc * 64 + lane), r = ci / CPRH, q = ci - r * CPRH;
+            __builtin_amdgcn_global_load_lds((pm_glb_char*)(ubase + (r * CPRH + (q ^ (r & SW))) * 16u), (pm_lds_char*)(dst + pc * 1024), 16, 0, 0);
+        }
+        return;
+    }
 #endif
     const int cpr = L.K_pad >> 2;                            // 16-byte chunks per weight row (64 at K = 256, 40 at K = 160)
     const int sw = (cpr & 15) == 0 ? 15 : 7;
@@ -339,7 +364,7 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         for (int l = 0; l < 5; ++l) biasbuf[l * PM_H + tid] = (Ls[l]->bias && (l < 4 || tid < 64)) ? Ls[l]->bias[tid] : 0.f;
     }
     if constexpr (NLU > 0) { if (tid < NLU * 32) biasbuf[5 * PM_H + tid] = p.lu.bias ? p.lu.bias[tid] : 0.f; }
-    pr_dma(NLU > 0 ? p.lu : p.in, 0, smc, wave, lane, 0);
+    pr_dma<(NLU > 0 ? NLU * 8 : KSIN * 8)>(NLU > 0 ? p.lu : p.in, 0, smc, wave, lane, 0);
     int grp = 1;                                             // which half of the waves issues the next chunk's pieces
 
     f16x8 ah[8], al[8], nh[8], nl[8];
@@ -412,7 +437,10 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
         PR_WAIT_T2
 #ifndef FC_PREMLP_DMA_LATE
-        if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+        if (nextL) {                                                    // (the next chunk is this layer's, or -- a layer's last chunk -- the first of a 256-wide layer: premlp_fusable)
+            if (nextL == &L) pr_dma<KSTAT * 8>(L, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            else pr_dma<64>(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+        }
 #endif
         grp ^= 1;
         after_dma();                                                    // (loads that must not sit in front of the wait above: they get this chunk's time to land)
@@ -439,7 +467,10 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 }
             }
 #ifdef FC_PREMLP_DMA_LATE
-            if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            if (nextL) {                                                    // (the next chunk is this layer's, or -- a layer's last chunk -- the first of a 256-wide layer: premlp_fusable)
+            if (nextL == &L) pr_dma<KSTAT * 8>(L, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            else pr_dma<64>(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+        }
 #endif
             buf ^= 1;
             return;
@@ -463,7 +494,10 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             }
         }
 #ifdef FC_PREMLP_DMA_LATE
-        if (nextL) pr_dma(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+        if (nextL) {                                                    // (the next chunk is this layer's, or -- a layer's last chunk -- the first of a 256-wide layer: premlp_fusable)
+            if (nextL == &L) pr_dma<KSTAT * 8>(L, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            else pr_dma<64>(*nextL, nextc, smc + (buf ^ 1) * PRB, wave, lane, grp);
+        }
 #endif
         buf ^= 1;
     };
@@ -571,8 +605,8 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             __builtin_amdgcn_s_barrier();                                   // ... everybody's; everybody is done reading the other stage
             PR_WAIT_T2
 #ifndef FC_PREMLP_DMA_LATE
-            if (c + 1 < NLU) pr_dma(p.lu, c + 1, smc + (buf ^ 1) * PRB, wave, lane, grp);
-            else pr_dma(p.in, 0, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            if (c + 1 < NLU) pr_dma<NLU * 8>(p.lu, c + 1, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            else pr_dma<KSIN * 8>(p.in, 0, smc + (buf ^ 1) * PRB, wave, lane, grp);
 #endif
             grp ^= 1;
             constexpr int cpr = NLU * 8;                                    // 16-byte chunks per weight row
@@ -596,8 +630,8 @@ __global__ __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 }
             }
 #ifdef FC_PREMLP_DMA_LATE
-            if (c + 1 < NLU) pr_dma(p.lu, c + 1, smc + (buf ^ 1) * PRB, wave, lane, grp);
-            else pr_dma(p.in, 0, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            if (c + 1 < NLU) pr_dma<NLU * 8>(p.lu, c + 1, smc + (buf ^ 1) * PRB, wave, lane, grp);
+            else pr_dma<KSIN * 8>(p.in, 0, smc + (buf ^ 1) * PRB, wave, lane, grp);
 #endif
             buf ^= 1;
         };
