@@ -13,7 +13,7 @@ print("$v", round(j["value"]), round(j["ms_per_step"],2), j["mean_nats"], j["bpd
 for k in j["kernels"][:4]: print("   ", k["kernel"][:60], k["launches"], round(k["ms_per_step"],2))
 PY
 done
-for v in ; do
+for v in A B; do
   cp profiles/micro/ab/libfcflow_$v.so flowcompare_amd/libfcflow.so
   timeout -k 10 300 python bench.py --config c4_dgcnn_attn_extra_affine --batch 16 --points 16384 --steps 3 --warmup 1 --train-steps 0 --no-cpu-baseline > $out/${tag}_${v}_bench_c5.json 2> $out/${tag}_${v}_bench_c5.err || exit 1
   python - <<PY
